@@ -1,0 +1,83 @@
+/*
+ * lvae.h -- C ABI of the MI355X-native latent-analysis library (liblvae.so, gfx950).
+ *
+ * The reference (ClaartjeBarkhof/language-transformer-vae) has no FFI: its boundary for this path is a
+ * set of plain Python functions on torch tensors.  Each entry point below is
+ * what a ctypes binding behind one of those functions calls; the comment on each names the reference
+ * function it replaces (path:line under NewsVAE/).  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - every pointer is DEVICE memory, float32, row-major contiguous, owned by the caller;
+ *  - the library never allocates user-visible memory: scratch comes in through `ws` / `ws_bytes`
+ *    (size from the matching *_workspace_bytes query; 256-byte aligned);
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous on it;
+ *  - return value: LVAE_OK (0) or a negative lvae_status; lvae_last_error() gives the text for the
+ *    calling thread.  No exceptions, no aborts;
+ *  - all log-densities are natural logs.
+ */
+#ifndef LVAE_H
+#define LVAE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    LVAE_OK = 0,
+    LVAE_ERR_INVALID = -1,     /* bad shape / null pointer / bad flag          */
+    LVAE_ERR_WORKSPACE = -2,   /* workspace missing, misaligned or too small   */
+    LVAE_ERR_HIP = -3,         /* a HIP runtime call failed                    */
+    LVAE_ERR_UNSUPPORTED = -4  /* valid request this build cannot serve        */
+} lvae_status;
+
+/* how the posterior spread array is parameterised */
+#define LVAE_SPREAD_LOGVAR 0   /* loss_and_optimisation.py: logvar              */
+#define LVAE_SPREAD_VAR 1      /* mutual_information.py: var / covariance diag  */
+
+/* which kernel family evaluates the pair matrix */
+#define LVAE_PATH_AUTO 0       /* MFMA unless the conditioning estimate says otherwise */
+#define LVAE_PATH_MFMA 1       /* fp32 MFMA quadratic expansion                */
+#define LVAE_PATH_DIRECT 2     /* VALU direct form (z-mu)^2 p, no cancellation */
+
+const char* lvae_last_error(void);
+int lvae_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Aggregate-posterior log-density:  for every sample i
+ *     log_qz[i]           = LSE_j  sum_d log N(z_id; mu_jd, var_jd)            - log_norm
+ *     log_qz_prod_marg[i] = sum_d ( LSE_j log N(z_id; mu_jd, var_jd) - log_norm )   (optional)
+ * Replaces approximate_log_q_z (loss_and_optimisation.py:139-221) and its [M,N,D] temporary; the
+ * host passes log_norm = log(N*dataset_size) ("chen", :207) or log(N) (:215).
+ * With exclude_diag != 0 the pair j == i + diag_offset is left out of the first reduction
+ * (mi_upper_bound's masked logsumexp, mutual_information.py:207-208).
+ * z [M,D]; mu, spread [N,D]; log_qz [M]; log_qz_prod_marg [M] or NULL.
+ * ------------------------------------------------------------------------------------------- */
+int lvae_log_qz_workspace_bytes(int64_t M, int64_t N, int D, int with_prod_marg, int64_t* out_bytes);
+int lvae_log_qz_f32(const float* z, const float* mu, const float* spread, int spread_kind,
+                    int64_t M, int64_t N, int D, float log_norm,
+                    int exclude_diag, int64_t diag_offset, int path,
+                    float* log_qz, float* log_qz_prod_marg,
+                    void* ws, int64_t ws_bytes, void* stream);
+
+/* Column-sharded variant: the same reduction over the posteriors handed in, returned un-normalised as
+ * (row_max, row_sum) with log_qz[i] = row_max[i] + log(row_sum[i]) - log_norm, so that partial results
+ * from several devices combine with all-reduce(max) + all-reduce(sum).
+ * No counterpart in the reference (it never shards this reduction). */
+int lvae_log_qz_partial_f32(const float* z, const float* mu, const float* spread, int spread_kind,
+                            int64_t M, int64_t N, int D, int path,
+                            float* row_max, float* row_sum,
+                            void* ws, int64_t ws_bytes, void* stream);
+
+/* q_z_estimate (mutual_information.py:44-52) including quirk Q2: the reduction runs over the SAMPLE
+ * axis:  out[j] = LSE_i log N(z_i; mu_j, var_j) - log_norm,  out [N].  Workspace: query with the
+ * roles swapped, lvae_log_qz_workspace_bytes(N, M, D, 0, ..). */
+int lvae_qz_estimate_f32(const float* z, const float* mu, const float* spread, int spread_kind,
+                         int64_t M, int64_t N, int D, float log_norm, float* out,
+                         void* ws, int64_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LVAE_H */

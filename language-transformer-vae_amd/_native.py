@@ -1,0 +1,88 @@
+"""ctypes binding of liblvae.so -- the C ABI declared in include/lvae.h.
+
+There is no fallback: if the shared library is missing or a call fails, this raises.  PyTorch is used
+only to own device memory and to name the current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblvae.so")
+
+SPREAD_LOGVAR, SPREAD_VAR = 0, 1
+PATH_AUTO, PATH_MFMA, PATH_DIRECT = 0, 1, 2
+
+_lib = None
+
+_c_f32p = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_f32 = ctypes.c_float
+
+_SIGNATURES = {
+    "lvae_last_error": (ctypes.c_char_p, []),
+    "lvae_version": (_int, []),
+    "lvae_log_qz_workspace_bytes": (_int, [_i64, _i64, _int, _int, ctypes.POINTER(_i64)]),
+    "lvae_log_qz_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _int, _i64, _i64, _int, _f32, _int, _i64, _int,
+                               _c_f32p, _c_f32p, ctypes.c_void_p, _i64, ctypes.c_void_p]),
+    "lvae_log_qz_partial_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _int, _i64, _i64, _int, _int,
+                                       _c_f32p, _c_f32p, ctypes.c_void_p, _i64, ctypes.c_void_p]),
+    "lvae_qz_estimate_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _int, _i64, _i64, _int, _f32, _c_f32p,
+                                    ctypes.c_void_p, _i64, ctypes.c_void_p]),
+}
+
+
+class LvaeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load liblvae.so once.  Raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LvaeError(f"{LIB_PATH} is missing: build it with `make -C {_HERE}/csrc` "
+                            "(there is no CPU or PyTorch fallback)")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(rc):
+    if rc != 0:
+        raise LvaeError(f"liblvae status {rc}: {lib().lvae_last_error().decode()}")
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def as_f32(t, name):
+    """The reference works in float32 on one device; keep that contract explicit."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if t.requires_grad:
+        raise LvaeError(f"{name} requires grad: the HIP path is forward-only (analysis path)")
+    if not t.is_cuda:
+        raise LvaeError(f"{name} is on {t.device}: the HIP path needs a GPU tensor (no CPU fallback)")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def workspace(nbytes, device):
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)

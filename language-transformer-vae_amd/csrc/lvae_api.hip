@@ -1,0 +1,219 @@
+// extern "C" entry points of liblvae.so (see include/lvae.h for the contract of each).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "pair_plan.h"
+
+// ---- launchers implemented in the kernel files --------------------------------------------------
+int lvae_launch_colsum(const float* mu, int64_t n, int D, PairHeader* hdr, hipStream_t st);
+int lvae_launch_prep(bool gauss, bool frag, const float* x, const float* spread, int spread_kind,
+                     int64_t n, int64_t npad, int D, int DP, PairHeader* hdr, int64_t ngauss,
+                     float* out, float* bias, float* dparams, int DC, hipStream_t st);
+int lvae_launch_prep_dparams(const float* mu, const float* spread, int spread_kind, int64_t n, int D,
+                             int DC, float* dparams, hipStream_t st);
+int lvae_launch_finalize(const float2* partial, int nsplit, int64_t cpad, int64_t C,
+                         const float* colbias, float log_norm, float* out, float* out_max,
+                         float* out_sum, const PairHeader* hdr, float cond_limit, int use_if_above,
+                         hipStream_t st);
+int lvae_launch_finalize_pm(const float2* partial, int nsplit, int64_t cpad, int64_t C, int D, int DC,
+                            float log_norm, float* out, hipStream_t st);
+int lvae_launch_pair_lse_mfma(const PairPlan& p, const float* rfrag, const float* rbias,
+                              const float* cop, float2* partial, const PairHeader* hdr,
+                              float cond_limit, int use_if_above, bool excl, int64_t excl_offset,
+                              hipStream_t st);
+int lvae_launch_pair_direct(const PairPlan& p, bool joint, bool pm, const float* z,
+                            const float* dparams, float2* partial, float2* partial_pm,
+                            const PairHeader* hdr, float cond_limit, int use_if_above, int excl,
+                            int64_t excl_offset, hipStream_t st);
+
+// ---- error text, per calling thread --------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+int lvae_set_error(int status, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return status;
+}
+
+extern "C" const char* lvae_last_error(void) { return g_err; }
+extern "C" int lvae_version(void) { return 100; }
+
+// Conditioning estimate above which the auto path leaves the MFMA expansion for the direct form.
+// prep computes  cond = max_j sum_d 0.5 * (2|mu_jd|/sigma_jd + 3)^2  -- the magnitude of the terms
+// that cancel in the expansion for a sample within ~3 sigma of posterior j (the only pairs that carry
+// weight in the logsumexp).  One fp32 ulp of that is the absolute error scale in nats:
+// 2^-23 * cond <= ~2.4e-3  <=>  cond <= 2e4.
+#define LVAE_COND_LIMIT 2.0e4f
+
+static int check_ws(const void* ws, int64_t ws_bytes, size_t need) {
+    if (!ws) return lvae_set_error(LVAE_ERR_WORKSPACE, "workspace pointer is NULL (need %zu bytes)", need);
+    if (((uintptr_t)ws & 255) != 0)
+        return lvae_set_error(LVAE_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    if (ws_bytes < 0 || (size_t)ws_bytes < need)
+        return lvae_set_error(LVAE_ERR_WORKSPACE, "workspace too small: %lld < %zu bytes",
+                              (long long)ws_bytes, need);
+    return LVAE_OK;
+}
+
+static int check_pair_shapes(const float* z, const float* mu, const float* spread, int spread_kind,
+                             int64_t M, int64_t N, int D) {
+    LVAE_CHECK_ARG(z && mu && spread, "z, mu and spread must be non-NULL");
+    LVAE_CHECK_ARG(M >= 1 && N >= 1, "need M >= 1 and N >= 1 (got M=%lld N=%lld)", (long long)M, (long long)N);
+    LVAE_CHECK_ARG(D >= 1 && D <= 4096, "need 1 <= D <= 4096 (got %d)", D);
+    LVAE_CHECK_ARG(M < (1LL << 31) && N < (1LL << 31), "M and N must be below 2^31");
+    LVAE_CHECK_ARG(spread_kind == LVAE_SPREAD_LOGVAR || spread_kind == LVAE_SPREAD_VAR,
+                   "spread_kind must be LVAE_SPREAD_LOGVAR or LVAE_SPREAD_VAR");
+    return LVAE_OK;
+}
+
+extern "C" int lvae_log_qz_workspace_bytes(int64_t M, int64_t N, int D, int with_prod_marg,
+                                           int64_t* out_bytes) {
+    LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
+    LVAE_CHECK_ARG(M >= 1 && N >= 1 && D >= 1 && D <= 4096, "bad shape M=%lld N=%lld D=%d",
+                   (long long)M, (long long)N, D);
+    const PairPlan p = lvae_make_pair_plan(N, M, D, with_prod_marg != 0);
+    *out_bytes = (int64_t)p.total;
+    return LVAE_OK;
+}
+
+// Shared driver: samples on the kept axis, posteriors on the reduced axis.
+static int run_log_qz(const float* z, const float* mu, const float* spread, int spread_kind,
+                      int64_t M, int64_t N, int D, float log_norm, int exclude_diag,
+                      int64_t diag_offset, int path, float* log_qz, float* log_qz_pm, float* row_max,
+                      float* row_sum, void* ws, int64_t ws_bytes, hipStream_t st) {
+    int rc = check_pair_shapes(z, mu, spread, spread_kind, M, N, D);
+    if (rc) return rc;
+    LVAE_CHECK_ARG(path == LVAE_PATH_AUTO || path == LVAE_PATH_MFMA || path == LVAE_PATH_DIRECT,
+                   "unknown path %d", path);
+    const bool with_pm = log_qz_pm != nullptr;
+    const PairPlan p = lvae_make_pair_plan(N, M, D, with_pm);
+    rc = check_ws(ws, ws_bytes, p.total);
+    if (rc) return rc;
+    if (path == LVAE_PATH_MFMA && p.DP == 0)
+        return lvae_set_error(LVAE_ERR_UNSUPPORTED, "MFMA path needs D <= 128 (got D=%d)", D);
+
+    char* base = (char*)ws;
+    PairHeader* hdr = (PairHeader*)(base + p.off_hdr);
+    float* rfrag = (float*)(base + p.off_rfrag);
+    float* rbias = (float*)(base + p.off_rbias);
+    float* cop = (float*)(base + p.off_cop);
+    float2* partial = (float2*)(base + p.off_partial);
+    float* dparams = (float*)(base + p.off_dparams);
+    float2* dpartial = (float2*)(base + p.off_dpartial);
+    float2* dpartial_pm = (float2*)(base + p.off_dpartial_pm);
+    const bool want_joint = log_qz || row_max;
+
+    // With prod-marginals requested the direct kernel visits every (i,j,d) term anyway and the joint
+    // density rides along for one add per term, so the MFMA kernel is only used when asked for.
+    int joint_path = path;
+    if (p.DP == 0) joint_path = LVAE_PATH_DIRECT;
+    else if (with_pm && path == LVAE_PATH_AUTO) joint_path = LVAE_PATH_DIRECT;
+    const bool need_mfma = want_joint && joint_path != LVAE_PATH_DIRECT;
+    const bool need_direct = with_pm || (want_joint && joint_path != LVAE_PATH_MFMA);
+
+    LVAE_HIP(hipMemsetAsync(hdr, 0, sizeof(PairHeader), st));
+    if (p.DP) {
+        rc = lvae_launch_colsum(mu, N, D, hdr, st);
+        if (rc) return rc;
+        rc = lvae_launch_prep(true, true, mu, spread, spread_kind, N, p.nblk * 32, D, p.DP, hdr, N,
+                              rfrag, rbias, need_direct ? dparams : nullptr, p.DC, st);
+        if (rc) return rc;
+        if (need_mfma) {
+            rc = lvae_launch_prep(false, false, z, nullptr, 0, M, p.cpad, D, p.DP, hdr, N, cop, nullptr,
+                                  nullptr, p.DC, st);
+            if (rc) return rc;
+        }
+    } else {
+        rc = lvae_launch_prep_dparams(mu, spread, spread_kind, N, D, p.DC, dparams, st);
+        if (rc) return rc;
+    }
+
+    const bool gated = want_joint && joint_path == LVAE_PATH_AUTO;
+    const float limit = gated ? LVAE_COND_LIMIT : -1.0f;
+    if (need_mfma) {
+        rc = lvae_launch_pair_lse_mfma(p, rfrag, rbias, cop, partial, hdr, limit, 0, exclude_diag != 0,
+                                       diag_offset, st);
+        if (rc) return rc;
+    }
+    if (need_direct) {
+        const bool djoint = want_joint && joint_path != LVAE_PATH_MFMA;
+        rc = lvae_launch_pair_direct(p, djoint, with_pm, z, dparams, dpartial, dpartial_pm, hdr, limit, 1,
+                                     exclude_diag, diag_offset, st);
+        if (rc) return rc;
+    }
+    if (want_joint) {
+        // gated: both pair kernels were launched and exactly one ran; the finalize of the other one
+        // exits on the same device-side test, so the outputs are written once.
+        if (joint_path != LVAE_PATH_DIRECT) {
+            rc = lvae_launch_finalize(partial, p.nsplit, p.cpad, M, nullptr, log_norm, log_qz, row_max,
+                                      row_sum, hdr, limit, 0, st);
+            if (rc) return rc;
+        }
+        if (joint_path != LVAE_PATH_MFMA) {
+            rc = lvae_launch_finalize(dpartial, p.dsplit, p.cpad, M, nullptr, log_norm, log_qz, row_max,
+                                      row_sum, hdr, limit, 1, st);
+            if (rc) return rc;
+        }
+    }
+    if (with_pm) {
+        rc = lvae_launch_finalize_pm(dpartial_pm, p.dsplit, p.cpad, M, D, p.DC, log_norm, log_qz_pm, st);
+        if (rc) return rc;
+    }
+    return LVAE_OK;
+}
+
+extern "C" int lvae_log_qz_f32(const float* z, const float* mu, const float* spread, int spread_kind,
+                               int64_t M, int64_t N, int D, float log_norm, int exclude_diag,
+                               int64_t diag_offset, int path, float* log_qz, float* log_qz_prod_marg,
+                               void* ws, int64_t ws_bytes, void* stream) {
+    LVAE_CHECK_ARG(log_qz || log_qz_prod_marg, "at least one of log_qz / log_qz_prod_marg is required");
+    return run_log_qz(z, mu, spread, spread_kind, M, N, D, log_norm, exclude_diag, diag_offset, path,
+                      log_qz, log_qz_prod_marg, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int lvae_log_qz_partial_f32(const float* z, const float* mu, const float* spread,
+                                       int spread_kind, int64_t M, int64_t N, int D, int path,
+                                       float* row_max, float* row_sum, void* ws, int64_t ws_bytes,
+                                       void* stream) {
+    LVAE_CHECK_ARG(row_max && row_sum, "row_max and row_sum must be non-NULL");
+    return run_log_qz(z, mu, spread, spread_kind, M, N, D, 0.f, 0, 0, path, nullptr, nullptr, row_max,
+                      row_sum, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// Roles swapped: posteriors on the kept axis (one output each), samples on the reduced axis.
+extern "C" int lvae_qz_estimate_f32(const float* z, const float* mu, const float* spread,
+                                    int spread_kind, int64_t M, int64_t N, int D, float log_norm,
+                                    float* out, void* ws, int64_t ws_bytes, void* stream) {
+    int rc = check_pair_shapes(z, mu, spread, spread_kind, M, N, D);
+    if (rc) return rc;
+    LVAE_CHECK_ARG(out, "out is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    const PairPlan p = lvae_make_pair_plan(M, N, D, false);
+    rc = check_ws(ws, ws_bytes, p.total);
+    if (rc) return rc;
+    if (p.DP == 0)
+        return lvae_set_error(LVAE_ERR_UNSUPPORTED, "q_z_estimate needs D <= 128 (got D=%d)", D);
+    char* base = (char*)ws;
+    PairHeader* hdr = (PairHeader*)(base + p.off_hdr);
+    float* rfrag = (float*)(base + p.off_rfrag);
+    float* rbias = (float*)(base + p.off_rbias);
+    float* cop = (float*)(base + p.off_cop);
+    float* colbias = (float*)(base + p.off_colbias);
+    float2* partial = (float2*)(base + p.off_partial);
+    LVAE_HIP(hipMemsetAsync(hdr, 0, sizeof(PairHeader), st));
+    rc = lvae_launch_colsum(mu, N, D, hdr, st);
+    if (rc) return rc;
+    rc = lvae_launch_prep(false, true, z, nullptr, 0, M, p.nblk * 32, D, p.DP, hdr, N, rfrag, rbias,
+                          nullptr, p.DC, st);
+    if (rc) return rc;
+    rc = lvae_launch_prep(true, false, mu, spread, spread_kind, N, p.cpad, D, p.DP, hdr, N, cop, colbias,
+                          nullptr, p.DC, st);
+    if (rc) return rc;
+    rc = lvae_launch_pair_lse_mfma(p, rfrag, rbias, cop, partial, hdr, -1.f, 0, false, 0, st);
+    if (rc) return rc;
+    return lvae_launch_finalize(partial, p.nsplit, p.cpad, N, colbias, log_norm, out, nullptr, nullptr,
+                                hdr, -1.f, 0, st);
+}

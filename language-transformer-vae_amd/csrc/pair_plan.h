@@ -1,0 +1,71 @@
+// Host-side plan for one "pair log-density + logsumexp" job: tile shapes, grid split and the
+// layout of the caller-provided workspace.  Shared by the MFMA path, the direct path and the API.
+#pragma once
+#include "lvae_common.h"
+
+// Lives at the start of the workspace; zeroed (hipMemsetAsync) at the start of every call.
+struct PairHeader {
+    double colsum[128];      // per-dimension sum of the posterior means (centering shift * R_gauss)
+    unsigned int cond_bits;  // float bits of max_j conditioning estimate (non-negative -> uint order)
+    unsigned int pad_[63];
+};
+
+struct PairPlan {
+    int64_t R;       // reduced axis length (posteriors for log q(z); samples for q_z_estimate)
+    int64_t C;       // kept axis length (one output per element)
+    int D, DP, NCB;  // latent dim, padded dim (0: MFMA path unsupported), column blocks per wave
+    int64_t nblk;    // 32-row blocks on the reduced axis
+    int64_t cpad;    // kept axis padded to the MFMA workgroup tile (multiple of 256 when DP == 0)
+    int nsplit;      // reduced-axis splits of the MFMA grid
+    int64_t blk_per_split;
+    int dsplit;      // reduced-axis splits of the direct grid
+    int64_t rows_per_dsplit;
+    bool with_pm;
+    int DC;          // padded dim of the direct-path parameters: 16/32/64, or a multiple of 16 above
+    // byte offsets into the workspace
+    size_t off_hdr, off_rfrag, off_rbias, off_cop, off_colbias, off_partial;
+    size_t off_dparams, off_dpartial, off_dpartial_pm, total;
+};
+
+static inline size_t lvae_align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool with_pm) {
+    PairPlan p{};
+    p.R = R; p.C = C; p.D = D; p.with_pm = with_pm;
+    p.DP = lvae_pad_dim(D);
+    p.NCB = (p.DP == 16) ? 4 : (p.DP == 32 ? 2 : 1);
+    p.nblk = lvae_ceil_div(R, 32);
+    const int64_t wg_cols = p.DP ? 4 * 32 * p.NCB : 256;
+    p.cpad = lvae_round_up(C, wg_cols < 256 ? 256 : wg_cols);
+    // MFMA grid: aim at two waves per SIMD on 256 CUs (2048 waves), never more splits than blocks
+    const int64_t col_waves = p.DP ? p.cpad / (32 * p.NCB) : 1;
+    int64_t ns = lvae_ceil_div(2048, col_waves);
+    if (ns > p.nblk) ns = p.nblk;
+    if (ns < 1) ns = 1;
+    if (ns > 64) ns = 64;
+    p.blk_per_split = lvae_ceil_div(p.nblk, ns);
+    p.nsplit = (int)lvae_ceil_div(p.nblk, p.blk_per_split);
+    // direct grid: one lane per kept element, 64 per wave
+    const int64_t dwaves = p.cpad / 64;
+    int64_t ds = lvae_ceil_div(4096, dwaves);
+    if (ds > lvae_ceil_div(R, 64)) ds = lvae_ceil_div(R, 64);
+    if (ds < 1) ds = 1;
+    if (ds > 64) ds = 64;
+    p.rows_per_dsplit = lvae_ceil_div(R, ds);
+    p.dsplit = (int)lvae_ceil_div(R, p.rows_per_dsplit);
+    p.DC = D <= 16 ? 16 : (D <= 32 ? 32 : (D <= 64 ? 64 : (int)lvae_round_up(D, 16)));
+
+    size_t o = 0;
+    p.off_hdr = o;      o = lvae_align256(o + sizeof(PairHeader));
+    p.off_rfrag = o;    o = lvae_align256(o + (size_t)p.nblk * (p.DP ? p.DP : 0) * 64 * sizeof(float));
+    p.off_rbias = o;    o = lvae_align256(o + (size_t)p.nblk * 32 * sizeof(float));
+    p.off_cop = o;      o = lvae_align256(o + (size_t)p.cpad * 2 * p.DP * sizeof(float));
+    p.off_colbias = o;  o = lvae_align256(o + (size_t)p.cpad * sizeof(float));
+    p.off_partial = o;  o = lvae_align256(o + (size_t)p.nsplit * p.cpad * 2 * sizeof(float));
+    p.off_dparams = o;  o = lvae_align256(o + (size_t)R * 3 * p.DC * sizeof(float));
+    p.off_dpartial = o; o = lvae_align256(o + (size_t)p.dsplit * p.cpad * 2 * sizeof(float));
+    p.off_dpartial_pm = o;
+    if (with_pm) o = lvae_align256(o + (size_t)p.dsplit * p.cpad * p.DC * 2 * sizeof(float));
+    p.total = o;
+    return p;
+}

@@ -1,0 +1,215 @@
+// Operand preparation and finalisation kernels for the pair log-density paths.
+//
+// The log-density of sample z under posterior (mu, var), scaled to base 2, is a bilinear form
+//     log2e * sum_d log N(z_d; mu_d, var_d) = sum_d [ z_d^2 * a_d + z_d * b_d ] + c
+//     a_d = -0.5 * log2e / var_d,  b_d = log2e * mu_d / var_d,
+//     c   = -0.5 * log2e * sum_d (mu_d^2 / var_d + log var_d + log 2pi)
+// so the N x M matrix is a [*, 2D] x [2D, *] contraction (half 0 = quadratic terms, half 1 = linear
+// terms) plus a per-posterior bias.  Both z and mu are first shifted by the per-dimension mean of mu
+// (the density only depends on z - mu), which keeps |mu| -- and with it the cancellation in the
+// expansion -- as small as a global shift can.
+//
+// Reduced-axis operands are written "fragment-major": for each block of 32 rows, DP/4 chunks of
+// [64 lanes][4 floats], exactly the order in which the lanes of a wave consume them as the A operand
+// of v_mfma_f32_32x32x2_f32 (lane = row + 32*half, MFMA step s = dimension s).  One wave-wide
+// 16-byte load per chunk is then a single contiguous 1 KiB read.
+#include "pair_plan.h"
+
+__global__ void colsum_kernel(const float* __restrict__ mu, int64_t n, int D, PairHeader* hdr,
+                              int rows_per_block) {
+    const int d = threadIdx.x;
+    if (d >= D) return;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > n) r1 = n;
+    double acc = 0.0;
+    for (int64_t r = r0; r < r1; ++r) acc += (double)mu[r * D + d];
+    atomicAdd(&hdr->colsum[d], acc);
+}
+
+// One thread per (padded) row.  GAUSS rows come from (mu, spread), SAMPLE rows from z.
+// FRAG selects the fragment-major reduced-axis layout, otherwise row-major [row][2*DP] (kept axis).
+template <bool GAUSS, bool FRAG>
+__global__ void prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ spread,
+                                    int spread_kind, int64_t n, int64_t npad, int D, int DP,
+                                    PairHeader* hdr, double inv_ngauss, float* __restrict__ out,
+                                    float* __restrict__ bias, float* __restrict__ dparams, int DC) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= npad) return;
+    const bool valid = row < n;
+    const int64_t blk = row >> 5;
+    const int r = (int)(row & 31);
+    float csum = 0.f, cond = 0.f;
+    for (int d = 0; d < DP; ++d) {
+        float v0 = 0.f, v1 = 0.f;
+        if (valid && d < D) {
+            const float shift = (float)(hdr->colsum[d] * inv_ngauss);
+            const float xv = x[row * D + d];
+            const float xs = xv - shift;
+            if (GAUSS) {
+                const float sp = spread[row * D + d];
+                const float logvar = spread_kind == LVAE_SPREAD_VAR ? logf(sp) : sp;
+                const float p = spread_kind == LVAE_SPREAD_VAR ? 1.0f / sp : expf(-sp);
+                v0 = -0.5f * LVAE_LOG2E * p;
+                v1 = LVAE_LOG2E * xs * p;
+                csum += xs * xs * p + logvar + LVAE_LOG_2PI;
+                const float t = 2.0f * fabsf(xs) * sqrtf(p) + 3.0f;
+                cond += 0.5f * t * t;
+                if (dparams) {
+                    dparams[(row * 3 + 0) * DC + d] = xv;
+                    dparams[(row * 3 + 1) * DC + d] = sqrtf(0.5f * LVAE_LOG2E * p);
+                    dparams[(row * 3 + 2) * DC + d] = -0.5f * LVAE_LOG2E * (logvar + LVAE_LOG_2PI);
+                }
+            } else {
+                v0 = xs * xs;
+                v1 = xs;
+            }
+        } else if (GAUSS && dparams && valid && d < DC) {
+            dparams[(row * 3 + 0) * DC + d] = 0.f;
+            dparams[(row * 3 + 1) * DC + d] = 0.f;
+            dparams[(row * 3 + 2) * DC + d] = 0.f;
+        }
+        if (FRAG) {
+            float* o = out + blk * (int64_t)DP * 64 + (d >> 2) * 256 + (d & 3);
+            o[r * 4] = v0;
+            o[(32 + r) * 4] = v1;
+        } else {
+            out[row * 2 * DP + d] = v0;
+            out[row * 2 * DP + DP + d] = v1;
+        }
+    }
+    if (bias) {
+        float b = GAUSS ? -0.5f * LVAE_LOG2E * csum : 0.f;
+        if (!valid) b = FRAG ? -INFINITY : 0.f;
+        bias[row] = b;
+    }
+    if (GAUSS && valid) atomicMax(&hdr->cond_bits, __float_as_uint(cond));
+}
+
+// Direct-path parameters only (used when the MFMA path is not available for this D).
+__global__ void prep_dparams_kernel(const float* __restrict__ mu, const float* __restrict__ spread,
+                                    int spread_kind, int64_t n, int D, int DC,
+                                    float* __restrict__ dparams) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * DC) return;
+    const int64_t row = idx / DC;
+    const int d = (int)(idx - row * DC);
+    float m = 0.f, w = 0.f, b = 0.f;
+    if (d < D) {
+        const float sp = spread[row * D + d];
+        const float logvar = spread_kind == LVAE_SPREAD_VAR ? logf(sp) : sp;
+        const float p = spread_kind == LVAE_SPREAD_VAR ? 1.0f / sp : expf(-sp);
+        m = mu[row * D + d];
+        w = sqrtf(0.5f * LVAE_LOG2E * p);
+        b = -0.5f * LVAE_LOG2E * (logvar + LVAE_LOG_2PI);
+    }
+    dparams[(row * 3 + 0) * DC + d] = m;
+    dparams[(row * 3 + 1) * DC + d] = w;
+    dparams[(row * 3 + 2) * DC + d] = b;
+}
+
+// Merge the per-split (max, sum) partials (base-2 domain) of one kept element into its result.
+//   out      : ln2 * (M + log2 S + colbias) - log_norm
+//   out_max / out_sum : un-normalised natural-log pair for cross-device combination
+__global__ void finalize_lse_kernel(const float2* __restrict__ partial, int nsplit, int64_t cpad,
+                                    int64_t C, const float* __restrict__ colbias, float log_norm,
+                                    float* __restrict__ out, float* __restrict__ out_max,
+                                    float* __restrict__ out_sum, const PairHeader* __restrict__ hdr,
+                                    float cond_limit, int use_if_above) {
+    if (cond_limit >= 0.f) {   // same path gate as the pair kernels
+        const float cond = __uint_as_float(hdr->cond_bits);
+        if ((cond > cond_limit) != (use_if_above != 0)) return;
+    }
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C) return;
+    float mx = -INFINITY;
+    for (int k = 0; k < nsplit; ++k) mx = fmaxf(mx, partial[k * cpad + i].x);
+    double s = 0.0;
+    for (int k = 0; k < nsplit; ++k) {
+        const float2 p = partial[k * cpad + i];
+        if (p.y > 0.f) s += (double)p.y * exp2((double)p.x - (double)mx);
+    }
+    const double cb = colbias ? (double)colbias[i] : 0.0;
+    if (out) out[i] = (float)(((double)mx + log2(s) + cb) * LVAE_LN2 - (double)log_norm);
+    if (out_max) {
+        out_max[i] = (float)(((double)mx + cb) * LVAE_LN2);
+        out_sum[i] = (float)s;
+    }
+}
+
+// Same for the product-of-marginals partials [dsplit][DC][cpad]:
+//   out[i] = sum_{d<D} ( ln2 * (M_d + log2 S_d) - log_norm )
+__global__ void finalize_pm_kernel(const float2* __restrict__ partial, int nsplit, int64_t cpad,
+                                   int64_t C, int D, int DC, float log_norm, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C) return;
+    double total = 0.0;
+    for (int d = 0; d < D; ++d) {
+        float mx = -INFINITY;
+        for (int k = 0; k < nsplit; ++k) mx = fmaxf(mx, partial[((int64_t)k * DC + d) * cpad + i].x);
+        double s = 0.0;
+        for (int k = 0; k < nsplit; ++k) {
+            const float2 p = partial[((int64_t)k * DC + d) * cpad + i];
+            if (p.y > 0.f) s += (double)p.y * exp2((double)p.x - (double)mx);
+        }
+        total += ((double)mx + log2(s)) * LVAE_LN2 - (double)log_norm;
+    }
+    out[i] = (float)total;
+}
+
+// ---- host launchers ----------------------------------------------------------------------------
+int lvae_launch_colsum(const float* mu, int64_t n, int D, PairHeader* hdr, hipStream_t st) {
+    const int rows_per_block = 256;
+    const int threads = (int)lvae_round_up(D, 64);
+    const int64_t blocks = lvae_ceil_div(n, rows_per_block);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, mu, n, D, hdr,
+                       rows_per_block);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+int lvae_launch_prep(bool gauss, bool frag, const float* x, const float* spread, int spread_kind,
+                     int64_t n, int64_t npad, int D, int DP, PairHeader* hdr, int64_t ngauss,
+                     float* out, float* bias, float* dparams, int DC, hipStream_t st) {
+    const int threads = 128;
+    const dim3 grid((unsigned)lvae_ceil_div(npad, threads));
+    const double inv = 1.0 / (double)ngauss;
+#define LVAE_PREP(G, F)                                                                          \
+    hipLaunchKernelGGL((prep_operand_kernel<G, F>), grid, dim3(threads), 0, st, x, spread,        \
+                       spread_kind, n, npad, D, DP, hdr, inv, out, bias, dparams, DC)
+    if (gauss && frag) LVAE_PREP(true, true);
+    else if (gauss) LVAE_PREP(true, false);
+    else if (frag) LVAE_PREP(false, true);
+    else LVAE_PREP(false, false);
+#undef LVAE_PREP
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+int lvae_launch_prep_dparams(const float* mu, const float* spread, int spread_kind, int64_t n, int D,
+                             int DC, float* dparams, hipStream_t st) {
+    const int64_t total = n * DC;
+    hipLaunchKernelGGL(prep_dparams_kernel, dim3((unsigned)lvae_ceil_div(total, 256)), dim3(256), 0,
+                       st, mu, spread, spread_kind, n, D, DC, dparams);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+int lvae_launch_finalize(const float2* partial, int nsplit, int64_t cpad, int64_t C,
+                         const float* colbias, float log_norm, float* out, float* out_max,
+                         float* out_sum, const PairHeader* hdr, float cond_limit, int use_if_above,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(finalize_lse_kernel, dim3((unsigned)lvae_ceil_div(C, 256)), dim3(256), 0, st,
+                       partial, nsplit, cpad, C, colbias, log_norm, out, out_max, out_sum, hdr,
+                       cond_limit, use_if_above);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+int lvae_launch_finalize_pm(const float2* partial, int nsplit, int64_t cpad, int64_t C, int D, int DC,
+                            float log_norm, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(finalize_pm_kernel, dim3((unsigned)lvae_ceil_div(C, 256)), dim3(256), 0, st,
+                       partial, nsplit, cpad, C, D, DC, log_norm, out);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
