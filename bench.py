@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Benchmark of the latent-analysis hot path: the aggregate-posterior log q(z) matrix with its streaming
+logsumexp, reduced to marginal KL / MI (BASELINE.json configs[1]: N = M = 65,536, D = 32, one MI355X).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of synthetic latents already resident in HBM:
+(N > 1: all-gather of the posterior parameters over RCCL) -> operand prep -> fused fp32-MFMA pair
+log-density + logsumexp -> per-sample log q(z|x), log p(z) -> float64 sums (N > 1: all-reduce) ->
+marginal KL and MI.  Multi-GPU runs are WEAK scaling: rows are sharded and N = M grows with sqrt(gpus)
+so that every GPU evaluates the same number of pairs (65,536^2) as the single-GPU run.
+
+Prints ONE JSON line (rank 0).  `value` is whole-job pair-evaluations per second.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters (dense fp32 matrix)
+BASE_N = 65536
+D = 32
+
+
+def problem_size(world):
+    """N = M so that N*M/world == BASE_N^2 (weak scaling), rounded to a multiple of 256*world."""
+    q = 256 * world
+    return max(q, int(round(BASE_N * math.sqrt(world) / q)) * q)
+
+
+def make_inputs(n_total, rank, world, device):
+    """SURVEY.md section 8(d) synthetic posteriors; every rank draws its own row block (seeded by rank)."""
+    n_local = n_total // world
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    mu = torch.randn(n_local, D, device=device, generator=g)
+    logvar = 0.5 * torch.randn(n_local, D, device=device, generator=g) - 1.0
+    eps = torch.randn(n_local, D, device=device, generator=g)
+    z = mu + eps * torch.exp(0.5 * logvar)
+    return mu, logvar, z
+
+
+def cpu_baseline(mu, logvar, z, log_norm, gpu_log_q_z, budget_s=12.0, max_rows=4096):
+    """Reference op chain (PyTorch eager, CPU) on a bounded row sample of the same workload."""
+    from oracle import torch_eager
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
+    torch.set_num_threads(threads)
+    mu_c, lv_c, z_c = mu.cpu(), logvar.cpu(), z[:max_rows].cpu()
+    rows, t_used, outs = 0, 0.0, []
+    torch_eager.log_qz_rows(mu_c, lv_c, z_c[:8], log_norm)          # warm-up
+    while rows < max_rows and t_used < budget_s:
+        t0 = time.perf_counter()
+        lq, _ = torch_eager.log_qz_rows(mu_c, lv_c, z_c[rows:rows + 64], log_norm)
+        t_used += time.perf_counter() - t0
+        outs.append(lq)
+        rows += 64
+    ref = torch.cat(outs).double()
+    got = gpu_log_q_z[:rows].double().cpu()
+    parity = float((got.mean() - ref.mean()).abs() / ref.mean().abs())
+    maxabs = float((got - ref).abs().max())
+    pairs = rows * mu_c.shape[0]
+    return {"value": pairs / t_used, "unit": "pair-evals/s", "cores": threads, "kind": "port",
+            "sample": f"PyTorch-eager restatement of approximate_log_q_z (oracle/torch_eager.py), "
+                      f"{rows} of {z.shape[0]} z rows x all {mu_c.shape[0]} posteriors, D={D}, fp32, "
+                      f"{t_used:.1f} s",
+            "parity_rel_mean_log_q_z": parity, "parity_max_abs": maxabs}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from lvae import _native as N
+    from lvae import distributed as LD
+    from lvae import estimators as E
+
+    n_total = problem_size(world)
+    mu, logvar, z = make_inputs(n_total, rank, world, device)
+    log_norm = math.log(n_total)
+    state = {}
+
+    def step():
+        if world > 1:
+            state["out"] = LD.sharded_latent_stats(mu, logvar, z, method="all")
+        else:
+            sums, lq = LD.hip_local_stats(mu, logvar, z, mu, logvar, log_norm, False)
+            s_lq, _, s_lp, s_lqx, cnt = sums.tolist()
+            state["out"] = {"marginal_kl": (s_lq - s_lp) / cnt, "mi": (s_lqx - s_lq) / cnt,
+                            "log_q_z_local": lq}
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    N.check(N.lib().lvae_profile_begin(args.steps))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    import ctypes
+    k_ms, k_n = ctypes.c_double(0), ctypes.c_int(0)
+    N.check(N.lib().lvae_profile_end(ctypes.byref(k_ms), ctypes.byref(k_n)))
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        pairs_total = float(n_total) * float(n_total)
+        ms_per_step = elapsed / args.steps * 1e3
+        value = pairs_total * args.steps / elapsed
+        pairs_rank = pairs_total / world
+        k_avg_ms = k_ms.value / max(k_n.value, 1)
+        achieved = 4.0 * D * pairs_rank / (k_avg_ms * 1e-3) / 1e12 if k_n.value else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and world == 1:
+            with open(tpath) as f:
+                traffic = json.load(f).get("pair_lse_mfma_kernel_hbm_bytes_per_launch")
+        line = {
+            "metric": "log q(z|x) pair-evals/sec at D=32", "value": value, "unit": "pair-evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: aggregate-posterior log q(z) matrix + logsumexp "
+                                   "-> marginal KL / MI, fused fp32 MFMA",
+                       "N": n_total, "M": n_total, "D": D, "pairs_per_gpu": pairs_rank,
+                       "parallelism": f"row-sharded x{world}, all-gather(mu,logvar)+all-reduce(sums)"},
+            "pct_of_fp32_mfma_peak": value * 4 * D / (world * FP32_MFMA_PEAK_TFLOPS * 1e12) * 100.0,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s",
+                         "frac": (achieved / FP32_MFMA_PEAK_TFLOPS) if achieved else None,
+                         "traffic": traffic, "kernel": "pair_lse_mfma_kernel<32,2,2,false>",
+                         "kernel_ms_avg": k_avg_ms, "launches": k_n.value,
+                         "flops_per_launch": 4.0 * D * pairs_rank},
+            "results": {k: v for k, v in state["out"].items() if isinstance(v, float)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(mu, logvar, z, log_norm, state["out"]["log_q_z_local"])
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -77,6 +77,47 @@ int lvae_qz_estimate_f32(const float* z, const float* mu, const float* spread, i
                          int64_t M, int64_t N, int D, float log_norm, float* out,
                          void* ws, int64_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Per-sample densities, reparameterised sampling and the importance-weighted reduction.
+ * ------------------------------------------------------------------------------------------- */
+
+/* sample_log_likelihood with reduce_latent_dim=True (loss_and_optimisation.py:79-110):
+ * z [B,K,D]; mu, logvar [B,D] (broadcast over K, :86-90).  log_q_z_x[b,k] = log N(z_bk; mu_b, var_b)
+ * (needs mu/logvar), log_p_z[b,k] = log N(z_bk; 0, I).  Either output may be NULL. */
+int lvae_sample_ll_f32(const float* z, const float* mu, const float* logvar, int64_t B, int64_t K,
+                       int D, float* log_q_z_x, float* log_p_z, void* stream);
+
+/* The same with reduce_latent_dim=False: out [B,K,D]; mu == NULL selects the prior branch (:99-101). */
+int lvae_sample_ll_elem_f32(const float* z, const float* mu, const float* logvar, int64_t B, int64_t K,
+                            int D, float* out, void* stream);
+
+/* Fused EncoderNewsVAE.reparameterize (modules/encoder.py:130-159, noise injected instead of drawn at
+ * :156) + the two densities of encode() (:93-98) + iw_log_p_x (loss_and_optimisation.py:783-794; twin
+ * utils_evaluation.py:176-180).  eps [B,K,D]; log_p_x_z [B,K] or NULL (treated as 0);
+ * outputs (each may be NULL): z [B,K,D], log_q_z_x, log_p_z [B,K], iw_ll [B]. */
+int lvae_reparam_iw_f32(const float* mu, const float* logvar, const float* eps, const float* log_p_x_z,
+                        int64_t B, int64_t K, int D, float* z, float* log_q_z_x, float* log_p_z,
+                        float* iw_ll, void* stream);
+
+/* iw_log_p_x alone (loss_and_optimisation.py:783-794): three [B,K] inputs -> [B]. */
+int lvae_iw_lse_f32(const float* log_p_x_z, const float* log_p_z, const float* log_q_z_x, int64_t B,
+                    int64_t K, float* out, void* stream);
+
+/* Deterministic reduction to one float64 in device memory: mode 0: scale*sum(x), mode 1:
+ * scale*sum(exp(x)).  Used for the `.mean()` the reference applies to per-sample vectors
+ * (loss_and_optimisation.py:108,:217-219).  Workspace: LVAE_REDUCE_WS_BYTES. */
+#define LVAE_REDUCE_WS_BYTES 8192
+int lvae_reduce_f32(const float* x, int64_t n, int mode, double scale, double* out, void* ws,
+                    int64_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Measurement aid (no counterpart in the reference): HIP events recorded on the caller's stream
+ * around the pair kernels of lvae_log_qz_f32 / lvae_log_qz_partial_f32, so a benchmark can time the
+ * dominant kernel alone.  lvae_profile_end synchronises on those events.
+ * ------------------------------------------------------------------------------------------- */
+int lvae_profile_begin(int max_launches);
+int lvae_profile_end(double* total_ms, int* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,7 +31,20 @@ _SIGNATURES = {
                                        _c_f32p, _c_f32p, ctypes.c_void_p, _i64, ctypes.c_void_p]),
     "lvae_qz_estimate_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _int, _i64, _i64, _int, _f32, _c_f32p,
                                     ctypes.c_void_p, _i64, ctypes.c_void_p]),
+    "lvae_sample_ll_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _i64, _int, _c_f32p, _c_f32p,
+                                  ctypes.c_void_p]),
+    "lvae_sample_ll_elem_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _i64, _int, _c_f32p,
+                                       ctypes.c_void_p]),
+    "lvae_reparam_iw_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _int, _c_f32p, _c_f32p,
+                                   _c_f32p, _c_f32p, ctypes.c_void_p]),
+    "lvae_iw_lse_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _i64, _c_f32p, ctypes.c_void_p]),
+    "lvae_reduce_f32": (_int, [_c_f32p, _i64, _int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
+                               _i64, ctypes.c_void_p]),
+    "lvae_profile_begin": (_int, [_int]),
+    "lvae_profile_end": (_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_int)]),
 }
+
+REDUCE_WS_BYTES = 8192
 
 
 class LvaeError(RuntimeError):
@@ -86,3 +99,20 @@ def as_f32(t, name):
 
 def workspace(nbytes, device):
     return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+def reduce_f64(x, mode=0, scale=1.0):
+    """scale * sum(x) (mode 0) or scale * sum(exp(x)) (mode 1) as a 0-dim float64 device tensor."""
+    x = as_f32(x, "x").reshape(-1)
+    dev = x.device
+    with torch.cuda.device(dev):
+        out = torch.empty((), dtype=torch.float64, device=dev)
+        ws = workspace(REDUCE_WS_BYTES, dev)
+        check(lib().lvae_reduce_f32(ptr(x), x.numel(), mode, float(scale), ptr(out), ptr(ws),
+                                    REDUCE_WS_BYTES, stream_ptr(dev)))
+    return out
+
+
+def mean_f32(x):
+    """Mean of a float32 device vector as a 0-dim float32 tensor (accumulated in float64 on device)."""
+    return reduce_f64(x, 0, 1.0 / x.numel()).float()

@@ -27,6 +27,16 @@ int lvae_launch_pair_direct(const PairPlan& p, bool joint, bool pm, const float*
                             const PairHeader* hdr, float cond_limit, int use_if_above, int excl,
                             int64_t excl_offset, hipStream_t st);
 
+int lvae_launch_reduce(int mode, const float* x, int64_t n, double scale, double* out, double* part,
+                       hipStream_t st);
+int lvae_launch_sample_iw(bool from_eps, const float* mu, const float* logvar, const float* src,
+                          const float* log_p_x_z, int64_t B, int64_t K, int D, float* z_out,
+                          float* log_q_z_x, float* log_p_z, float* iw_ll, hipStream_t st);
+int lvae_launch_sample_ll_elem(const float* mu, const float* logvar, const float* z, int64_t B,
+                               int64_t K, int D, float* out, hipStream_t st);
+int lvae_launch_iw_lse(const float* a, const float* b, const float* c, int64_t B, int64_t K, float* out,
+                       hipStream_t st);
+
 // ---- error text, per calling thread --------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
@@ -40,6 +50,61 @@ int lvae_set_error(int status, const char* fmt, ...) {
 
 extern "C" const char* lvae_last_error(void) { return g_err; }
 extern "C" int lvae_version(void) { return 100; }
+
+// ---- optional per-launch timing of the dominant (pair) kernels ------------------------------------
+// HIP events recorded on the caller's stream right around the pair kernels, so a benchmark can price
+// the dominant kernel alone while timing whole calls.  Off by default; not thread-safe by design
+// (a measurement facility, one measuring thread).
+#include <mutex>
+#include <vector>
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<hipEvent_t> g_prof_ev;   // start/stop pairs
+static int g_prof_used = 0;
+
+extern "C" int lvae_profile_begin(int max_launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    LVAE_CHECK_ARG(max_launches >= 1 && max_launches <= 65536, "max_launches out of range");
+    while ((int)g_prof_ev.size() < 2 * max_launches) {
+        hipEvent_t e;
+        LVAE_HIP(hipEventCreate(&e));
+        g_prof_ev.push_back(e);
+    }
+    g_prof_used = 0;
+    g_prof_on = true;
+    return LVAE_OK;
+}
+
+extern "C" int lvae_profile_end(double* total_ms, int* launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    LVAE_CHECK_ARG(total_ms && launches, "NULL output");
+    g_prof_on = false;
+    double tot = 0.0;
+    for (int i = 0; i < g_prof_used; ++i) {
+        LVAE_HIP(hipEventSynchronize(g_prof_ev[2 * i + 1]));
+        float ms = 0.f;
+        LVAE_HIP(hipEventElapsedTime(&ms, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = g_prof_used;
+    g_prof_used = 0;
+    return LVAE_OK;
+}
+
+static hipEvent_t prof_mark(hipStream_t st, hipEvent_t open) {
+    // open == nullptr: start a bracket, returns the stop event to record later (or nullptr when off)
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (open) {
+        (void)hipEventRecord(open, st);
+        return nullptr;
+    }
+    if (!g_prof_on || 2 * (g_prof_used + 1) > (int)g_prof_ev.size()) return nullptr;
+    hipEvent_t a = g_prof_ev[2 * g_prof_used], b = g_prof_ev[2 * g_prof_used + 1];
+    ++g_prof_used;
+    (void)hipEventRecord(a, st);
+    return b;
+}
 
 // Conditioning estimate above which the auto path leaves the MFMA expansion for the direct form.
 // prep computes  cond = max_j sum_d 0.5 * (2|mu_jd|/sigma_jd + 3)^2  -- the magnitude of the terms
@@ -133,6 +198,7 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
 
     const bool gated = want_joint && joint_path == LVAE_PATH_AUTO;
     const float limit = gated ? LVAE_COND_LIMIT : -1.0f;
+    hipEvent_t prof_stop = prof_mark(st, nullptr);
     if (need_mfma) {
         rc = lvae_launch_pair_lse_mfma(p, rfrag, rbias, cop, partial, hdr, limit, 0, exclude_diag != 0,
                                        diag_offset, st);
@@ -144,6 +210,7 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
                                      exclude_diag, diag_offset, st);
         if (rc) return rc;
     }
+    if (prof_stop) prof_mark(st, prof_stop);
     if (want_joint) {
         // gated: both pair kernels were launched and exactly one ran; the finalize of the other one
         // exits on the same device-side test, so the outputs are written once.
@@ -216,4 +283,61 @@ extern "C" int lvae_qz_estimate_f32(const float* z, const float* mu, const float
     if (rc) return rc;
     return lvae_launch_finalize(partial, p.nsplit, p.cpad, N, colbias, log_norm, out, nullptr, nullptr,
                                 hdr, -1.f, 0, st);
+}
+
+// ---- per-sample densities / sampling / IW ----------------------------------------------------------
+static int check_bkd(int64_t B, int64_t K, int D) {
+    LVAE_CHECK_ARG(B >= 1 && K >= 1 && D >= 1, "need B, K, D >= 1 (got B=%lld K=%lld D=%d)", (long long)B,
+                   (long long)K, D);
+    LVAE_CHECK_ARG(B < (1LL << 31), "B must be below 2^31");
+    return LVAE_OK;
+}
+
+extern "C" int lvae_sample_ll_f32(const float* z, const float* mu, const float* logvar, int64_t B,
+                                  int64_t K, int D, float* log_q_z_x, float* log_p_z, void* stream) {
+    int rc = check_bkd(B, K, D);
+    if (rc) return rc;
+    LVAE_CHECK_ARG(z, "z is NULL");
+    LVAE_CHECK_ARG(log_q_z_x || log_p_z, "no output requested");
+    LVAE_CHECK_ARG(!log_q_z_x || (mu && logvar), "log_q_z_x needs mu and logvar");
+    LVAE_CHECK_ARG((mu == nullptr) == (logvar == nullptr), "mu and logvar must come together");
+    return lvae_launch_sample_iw(false, mu, logvar, z, nullptr, B, K, D, nullptr, log_q_z_x, log_p_z,
+                                 nullptr, (hipStream_t)stream);
+}
+
+extern "C" int lvae_sample_ll_elem_f32(const float* z, const float* mu, const float* logvar, int64_t B,
+                                       int64_t K, int D, float* out, void* stream) {
+    int rc = check_bkd(B, K, D);
+    if (rc) return rc;
+    LVAE_CHECK_ARG(z && out, "z and out must be non-NULL");
+    LVAE_CHECK_ARG((mu == nullptr) == (logvar == nullptr), "mu and logvar must come together");
+    return lvae_launch_sample_ll_elem(mu, logvar, z, B, K, D, out, (hipStream_t)stream);
+}
+
+extern "C" int lvae_reparam_iw_f32(const float* mu, const float* logvar, const float* eps,
+                                   const float* log_p_x_z, int64_t B, int64_t K, int D, float* z,
+                                   float* log_q_z_x, float* log_p_z, float* iw_ll, void* stream) {
+    int rc = check_bkd(B, K, D);
+    if (rc) return rc;
+    LVAE_CHECK_ARG(mu && logvar && eps, "mu, logvar and eps must be non-NULL");
+    LVAE_CHECK_ARG(z || log_q_z_x || log_p_z || iw_ll, "no output requested");
+    return lvae_launch_sample_iw(true, mu, logvar, eps, log_p_x_z, B, K, D, z, log_q_z_x, log_p_z, iw_ll,
+                                 (hipStream_t)stream);
+}
+
+extern "C" int lvae_iw_lse_f32(const float* log_p_x_z, const float* log_p_z, const float* log_q_z_x,
+                               int64_t B, int64_t K, float* out, void* stream) {
+    LVAE_CHECK_ARG(B >= 1 && K >= 1, "need B, K >= 1");
+    LVAE_CHECK_ARG(log_p_x_z && log_p_z && log_q_z_x && out, "NULL pointer");
+    return lvae_launch_iw_lse(log_p_x_z, log_p_z, log_q_z_x, B, K, out, (hipStream_t)stream);
+}
+
+extern "C" int lvae_reduce_f32(const float* x, int64_t n, int mode, double scale, double* out, void* ws,
+                               int64_t ws_bytes, void* stream) {
+    LVAE_CHECK_ARG(x && out, "NULL pointer");
+    LVAE_CHECK_ARG(n >= 1, "need n >= 1");
+    LVAE_CHECK_ARG(mode == 0 || mode == 1, "mode must be 0 (sum) or 1 (sum exp)");
+    int rc = check_ws(ws, ws_bytes, LVAE_REDUCE_WS_BYTES);
+    if (rc) return rc;
+    return lvae_launch_reduce(mode, x, n, scale, out, (double*)ws, (hipStream_t)stream);
 }

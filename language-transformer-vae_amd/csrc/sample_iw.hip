@@ -1,0 +1,227 @@
+// Per-sample Gaussian log-densities, the reparameterised draw and the importance-weighted
+// log-likelihood reduction.  All HBM-bound streaming passes over [B,K,D] (eps and/or z) with
+// 16-byte-per-lane coalesced accesses: G = D/4 adjacent lanes share one sample row and reduce the
+// latent dimension with wave shuffles; the K axis is folded into a per-thread online logsumexp that is
+// merged across the workgroup through LDS.
+//
+//   z          = mu + eps * exp(0.5*logvar)                      modules/encoder.py:148-157
+//   log_q_z_x  = sum_d -0.5*(logvar + log 2pi + (z-mu)^2/var)    loss_and_optimisation.py:93-96,105
+//   log_p_z    = sum_d -0.5*(log 2pi + z^2)                      loss_and_optimisation.py:99-101,105
+//   iw_ll[b]   = LSE_k(log_p_x_z + log_p_z - log_q_z_x) - log K  loss_and_optimisation.py:783-794
+//
+// Algorithmic bytes per (sentence, sample): 4*D (eps) + 4 (log_p_x_z) read, + 4*D when z is written.
+#include "lvae_common.h"
+
+__device__ __forceinline__ float group_sum(float v, int G) {
+    for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void lse_push(float& m, float& s, float w) {
+    if (w > m) {
+        s = s * __expf(m - w) + 1.0f;
+        m = w;
+    } else {
+        s += __expf(w - m);
+    }
+}
+
+// MODE_EPS: the row source is eps (z is computed); otherwise the row source is z itself.
+// One workgroup per sentence b; G lanes per sample row (G = D/4, power of two <= 64).
+template <bool FROM_EPS>
+__global__ void __launch_bounds__(256)
+sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                 const float* __restrict__ src, const float* __restrict__ log_p_x_z, int64_t K, int D,
+                 int G, float* __restrict__ z_out, float* __restrict__ log_q_z_x,
+                 float* __restrict__ log_p_z, float* __restrict__ iw_ll) {
+    const int64_t b = blockIdx.x;
+    const int gl = threadIdx.x % G;          // lane inside the row group: owns dims 4*gl .. 4*gl+3
+    const int row_in_blk = threadIdx.x / G;
+    const int rows_per_iter = 256 / G;
+    const bool have_post = mu != nullptr;
+    f32x4 m4 = {0.f, 0.f, 0.f, 0.f}, lv4 = m4, sd4 = m4, iv4 = m4;
+    if (have_post) {
+        m4 = *reinterpret_cast<const f32x4*>(mu + b * D + 4 * gl);
+        lv4 = *reinterpret_cast<const f32x4*>(logvar + b * D + 4 * gl);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sd4[e] = expf(0.5f * lv4[e]);
+            iv4[e] = expf(lv4[e]);
+        }
+    }
+    float lm = -INFINITY, ls = 0.f;
+    const float* __restrict__ base = src + b * K * D;
+    for (int64_t k0 = 0; k0 < K; k0 += rows_per_iter) {
+        const int64_t k = k0 + row_in_blk;
+        const bool ok = k < K;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(base + k * D + 4 * gl);
+        f32x4 zz;
+        float lq = 0.f, lp = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // separate multiply and add, like the reference (no fused contraction)
+            zz[e] = FROM_EPS ? __fadd_rn(m4[e], __fmul_rn(v[e], sd4[e])) : v[e];
+            if (have_post) {
+                const float df = zz[e] - m4[e];
+                lq += -0.5f * (lv4[e] + LVAE_LOG_2PI + __fdiv_rn(df * df, iv4[e]));
+            }
+            lp += -0.5f * (LVAE_LOG_2PI + zz[e] * zz[e]);
+        }
+        if (FROM_EPS && z_out && ok) *reinterpret_cast<f32x4*>(z_out + (b * K + k) * D + 4 * gl) = zz;
+        lq = group_sum(lq, G);
+        lp = group_sum(lp, G);
+        if (ok && gl == 0) {
+            if (log_q_z_x) log_q_z_x[b * K + k] = lq;
+            if (log_p_z) log_p_z[b * K + k] = lp;
+            if (iw_ll) {
+                const float w = (log_p_x_z ? log_p_x_z[b * K + k] : 0.f) + lp - lq;
+                lse_push(lm, ls, w);
+            }
+        }
+    }
+    if (iw_ll) {
+        __shared__ float sm_m[256], sm_s[256];
+        sm_m[threadIdx.x] = lm;
+        sm_s[threadIdx.x] = ls;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float mx = -INFINITY;
+            for (int t = 0; t < 256; t += G) mx = fmaxf(mx, sm_m[t]);
+            double s = 0.0;
+            for (int t = 0; t < 256; t += G)
+                if (sm_s[t] > 0.f) s += (double)sm_s[t] * exp((double)sm_m[t] - (double)mx);
+            iw_ll[b] = (float)((double)mx + log(s) - log((double)K));
+        }
+    }
+}
+
+// Any D: one lane per sample row, scalar loads.
+template <bool FROM_EPS>
+__global__ void __launch_bounds__(256)
+sample_iw_generic_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                         const float* __restrict__ src, const float* __restrict__ log_p_x_z, int64_t K,
+                         int D, float* __restrict__ z_out, float* __restrict__ log_q_z_x,
+                         float* __restrict__ log_p_z, float* __restrict__ iw_ll) {
+    const int64_t b = blockIdx.x;
+    const bool have_post = mu != nullptr;
+    float lm = -INFINITY, ls = 0.f;
+    for (int64_t k = threadIdx.x; k < K; k += 256) {
+        float lq = 0.f, lp = 0.f;
+        for (int d = 0; d < D; ++d) {
+            const float v = src[(b * K + k) * D + d];
+            float zz = v;
+            if (have_post) {
+                const float mm = mu[b * D + d], lv = logvar[b * D + d];
+                if (FROM_EPS) zz = __fadd_rn(mm, __fmul_rn(v, expf(0.5f * lv)));
+                const float df = zz - mm;
+                lq += -0.5f * (lv + LVAE_LOG_2PI + __fdiv_rn(df * df, expf(lv)));
+            }
+            lp += -0.5f * (LVAE_LOG_2PI + zz * zz);
+            if (FROM_EPS && z_out) z_out[(b * K + k) * D + d] = zz;
+        }
+        if (log_q_z_x) log_q_z_x[b * K + k] = lq;
+        if (log_p_z) log_p_z[b * K + k] = lp;
+        if (iw_ll) lse_push(lm, ls, (log_p_x_z ? log_p_x_z[b * K + k] : 0.f) + lp - lq);
+    }
+    if (iw_ll) {
+        __shared__ float sm_m[256], sm_s[256];
+        sm_m[threadIdx.x] = lm;
+        sm_s[threadIdx.x] = ls;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float mx = -INFINITY;
+            for (int t = 0; t < 256; ++t) mx = fmaxf(mx, sm_m[t]);
+            double s = 0.0;
+            for (int t = 0; t < 256; ++t)
+                if (sm_s[t] > 0.f) s += (double)sm_s[t] * exp((double)sm_m[t] - (double)mx);
+            iw_ll[b] = (float)((double)mx + log(s) - log((double)K));
+        }
+    }
+}
+
+// Element-wise (no latent reduction): sample_log_likelihood(..., reduce_latent_dim=False).
+__global__ void __launch_bounds__(256)
+sample_ll_elem_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                      const float* __restrict__ z, int64_t total, int64_t KD, int D,
+                      float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const float zz = z[i];
+    if (mu) {
+        const int64_t b = i / KD;
+        const int d = (int)(i % D);
+        const float mm = mu[b * D + d], lv = logvar[b * D + d];
+        const float df = zz - mm;
+        out[i] = -0.5f * (lv + LVAE_LOG_2PI + __fdiv_rn(df * df, expf(lv)));
+    } else {
+        out[i] = -0.5f * (LVAE_LOG_2PI + zz * zz);
+    }
+}
+
+// logsumexp over the K axis of (a + b - c), minus log K:  [B,K] x 3 -> [B].  One wave per row.
+__global__ void __launch_bounds__(256)
+iw_lse_kernel(const float* __restrict__ log_p_x_z, const float* __restrict__ log_p_z,
+              const float* __restrict__ log_q_z_x, int64_t B, int64_t K, float* __restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    float lm = -INFINITY, ls = 0.f;
+    for (int64_t k = lane; k < K; k += 64) {
+        const float w = log_p_x_z[b * K + k] + log_p_z[b * K + k] - log_q_z_x[b * K + k];
+        lse_push(lm, ls, w);
+    }
+    const float mx = wave_max(lm);
+    double s = ls > 0.f ? (double)ls * exp((double)lm - (double)mx) : 0.0;
+    s = wave_sum_d(s);
+    if (lane == 0) out[b] = (float)((double)mx + log(s) - log((double)K));
+}
+
+static bool vec_ok(int D, int* G) {
+    if (D % 4 != 0) return false;
+    const int g = D / 4;
+    if (g > 64 || (g & (g - 1)) != 0) return false;
+    *G = g;
+    return true;
+}
+
+int lvae_launch_sample_iw(bool from_eps, const float* mu, const float* logvar, const float* src,
+                          const float* log_p_x_z, int64_t B, int64_t K, int D, float* z_out,
+                          float* log_q_z_x, float* log_p_z, float* iw_ll, hipStream_t st) {
+    int G = 0;
+    const dim3 grid((unsigned)B);
+    if (vec_ok(D, &G)) {
+        if (from_eps)
+            hipLaunchKernelGGL(sample_iw_kernel<true>, grid, dim3(256), 0, st, mu, logvar, src, log_p_x_z,
+                               K, D, G, z_out, log_q_z_x, log_p_z, iw_ll);
+        else
+            hipLaunchKernelGGL(sample_iw_kernel<false>, grid, dim3(256), 0, st, mu, logvar, src,
+                               log_p_x_z, K, D, G, z_out, log_q_z_x, log_p_z, iw_ll);
+    } else {
+        if (from_eps)
+            hipLaunchKernelGGL(sample_iw_generic_kernel<true>, grid, dim3(256), 0, st, mu, logvar, src,
+                               log_p_x_z, K, D, z_out, log_q_z_x, log_p_z, iw_ll);
+        else
+            hipLaunchKernelGGL(sample_iw_generic_kernel<false>, grid, dim3(256), 0, st, mu, logvar, src,
+                               log_p_x_z, K, D, z_out, log_q_z_x, log_p_z, iw_ll);
+    }
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+int lvae_launch_sample_ll_elem(const float* mu, const float* logvar, const float* z, int64_t B,
+                               int64_t K, int D, float* out, hipStream_t st) {
+    const int64_t total = B * K * D;
+    hipLaunchKernelGGL(sample_ll_elem_kernel, dim3((unsigned)lvae_ceil_div(total, 256)), dim3(256), 0,
+                       st, mu, logvar, z, total, K * D, D, out);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+int lvae_launch_iw_lse(const float* a, const float* b, const float* c, int64_t B, int64_t K, float* out,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(iw_lse_kernel, dim3((unsigned)lvae_ceil_div(B, 4)), dim3(256), 0, st, a, b, c, B,
+                       K, out);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}

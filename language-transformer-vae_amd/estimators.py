@@ -50,6 +50,92 @@ def approximate_log_q_z(mu, logvar, latent_z, method="chen", dataset_size=42068,
     log_norm = math.log(x_batch * dataset_size) if method == "chen" else math.log(x_batch)   # :207,:215
     log_q_z, log_q_z_prod_marg = log_qz_raw(mu, logvar, latent_z, log_norm, prod_marginals, path=path)
     if reduce_mean:
-        log_q_z = log_q_z.mean()
-        log_q_z_prod_marg = log_q_z_prod_marg.mean()     # Q1: None.mean() when prod_marginals=False
+        if log_q_z_prod_marg is None:                    # Q1, :219 -- ``None.mean()``
+            raise AttributeError("'NoneType' object has no attribute 'mean'")
+        log_q_z = N.mean_f32(log_q_z)
+        log_q_z_prod_marg = N.mean_f32(log_q_z_prod_marg)
     return log_q_z, log_q_z_prod_marg
+
+
+def sample_log_likelihood(latent_z, mu=None, logvar=None, reduce_latent_dim=True, reduce_batch_dim=True):
+    """loss_and_optimisation.py:79-110.  Log-density of samples under the posterior N(mu, exp(logvar))
+    (both given) or the standard-normal prior (neither given).
+    Supported layouts: latent_z [B,K,D] with mu/logvar [B,D] or [B,1,D] (:86-90), latent_z [M,D] with
+    mu/logvar [M,D], and any [..., D] for the prior."""
+    z = N.as_f32(latent_z, "latent_z")
+    post = mu is not None and logvar is not None
+    D = z.shape[-1]
+    dev = z.device
+    if post:
+        mu, logvar = N.as_f32(mu, "mu"), N.as_f32(logvar, "logvar")
+        if z.dim() == 3:
+            mu2 = mu.reshape(mu.shape[0], D) if mu.dim() == 3 and mu.shape[1] == 1 else mu
+            lv2 = logvar.reshape(logvar.shape[0], D) if logvar.dim() == 3 and logvar.shape[1] == 1 else logvar
+            if mu2.dim() != 2 or mu2.shape != (z.shape[0], D) or lv2.shape != mu2.shape:
+                raise ValueError(f"unsupported broadcast: latent_z {tuple(z.shape)}, mu {tuple(mu.shape)}")
+            B, K = z.shape[0], z.shape[1]
+        elif z.dim() == 2:
+            if mu.shape != z.shape or logvar.shape != z.shape:
+                raise ValueError(f"unsupported broadcast: latent_z {tuple(z.shape)}, mu {tuple(mu.shape)}")
+            mu2, lv2, B, K = mu, logvar, z.shape[0], 1
+        else:
+            raise ValueError("latent_z must be [B,K,D] or [M,D] for the posterior branch")
+        mu2, lv2 = mu2.contiguous(), lv2.contiguous()
+    else:
+        mu2 = lv2 = None
+        B, K = z.numel() // D, 1
+    with torch.cuda.device(dev):
+        if reduce_latent_dim:
+            out = torch.empty(z.shape[:-1], dtype=torch.float32, device=dev)
+            N.check(N.lib().lvae_sample_ll_f32(N.ptr(z), N.ptr(mu2), N.ptr(lv2), B, K, D,
+                                               N.ptr(out) if post else None,
+                                               None if post else N.ptr(out), N.stream_ptr(dev)))
+        else:
+            out = torch.empty_like(z)
+            N.check(N.lib().lvae_sample_ll_elem_f32(N.ptr(z), N.ptr(mu2), N.ptr(lv2), B, K, D, N.ptr(out),
+                                                    N.stream_ptr(dev)))
+    if reduce_batch_dim:                                  # :107-108 mean over dim 0
+        if out.dim() <= 1:
+            return N.mean_f32(out)
+        flat = out.reshape(out.shape[0], -1)
+        cols = torch.stack([N.mean_f32(flat[:, c]) for c in range(flat.shape[1])]) \
+            if flat.shape[1] <= 64 else flat.mean(dim=0)
+        return cols.reshape(out.shape[1:])
+    return out
+
+
+def iw_log_p_x(log_p_x_z, log_p_z, log_q_z_x):
+    """LossTermManager.iw_log_p_x (loss_and_optimisation.py:783-794; twin utils_evaluation.py:176-180):
+    logsumexp_k(log_p_x_z + log_p_z - log_q_z_x) - log K.  All inputs [batch, n_samples] -> [batch]."""
+    a, b, c = (N.as_f32(t, n) for t, n in ((log_p_x_z, "log_p_x_z"), (log_p_z, "log_p_z"),
+                                           (log_q_z_x, "log_q_z_x")))
+    if a.dim() != 2 or a.shape != b.shape or a.shape != c.shape:
+        raise ValueError("log_p_x_z, log_p_z, log_q_z_x must share one [batch, n_samples] shape")
+    B, K = a.shape
+    dev = a.device
+    with torch.cuda.device(dev):
+        out = torch.empty(B, dtype=torch.float32, device=dev)
+        N.check(N.lib().lvae_iw_lse_f32(N.ptr(a), N.ptr(b), N.ptr(c), B, K, N.ptr(out), N.stream_ptr(dev)))
+    return out
+
+
+def reparam_iw(mu, logvar, eps, log_p_x_z=None, return_z=True):
+    """Fused reparameterize + log q(z|x) + log p(z) + IW log-likelihood (modules/encoder.py:148-157,
+    :93-98; loss_and_optimisation.py:783-794) on injected noise ``eps`` [B,K,D].
+    Returns dict(latent_z, log_q_z_x, log_p_z, iw_ll)."""
+    mu, logvar, eps = N.as_f32(mu, "mu"), N.as_f32(logvar, "logvar"), N.as_f32(eps, "eps")
+    if eps.dim() != 3 or mu.shape != (eps.shape[0], eps.shape[2]) or logvar.shape != mu.shape:
+        raise ValueError("need eps [B,K,D] and mu/logvar [B,D]")
+    B, K, D = eps.shape
+    dev = eps.device
+    lpxz = None if log_p_x_z is None else N.as_f32(log_p_x_z, "log_p_x_z")
+    if lpxz is not None and lpxz.shape != (B, K):
+        raise ValueError("log_p_x_z must be [B,K]")
+    with torch.cuda.device(dev):
+        z = torch.empty_like(eps) if return_z else None
+        lq = torch.empty(B, K, dtype=torch.float32, device=dev)
+        lp = torch.empty(B, K, dtype=torch.float32, device=dev)
+        iw = torch.empty(B, dtype=torch.float32, device=dev)
+        N.check(N.lib().lvae_reparam_iw_f32(N.ptr(mu), N.ptr(logvar), N.ptr(eps), N.ptr(lpxz), B, K, D,
+                                            N.ptr(z), N.ptr(lq), N.ptr(lp), N.ptr(iw), N.stream_ptr(dev)))
+    return {"latent_z": z, "log_q_z_x": lq, "log_p_z": lp, "iw_ll": iw}

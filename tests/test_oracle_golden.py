@@ -153,3 +153,38 @@ def test_tts_mmd_self_consistency():
     assert mmd > 0.01
     same = onp.mmd_statistic_tts(a, rng.standard_normal((50, 8)), alphas)
     assert abs(same) < mmd / 5
+
+
+# ---- the plain-C oracle is pinned to the same golden vectors ------------------------------------
+@pytest.mark.parametrize("case", LOGQZ_CASES)
+def test_c_oracle_log_qz(case):
+    import math
+    from oracle import oracle_c
+    g = load_golden("logqz_" + case)
+    tol = dict(rtol=1e-4, atol=2e-3) if case in ("peaked", "far") else dict(rtol=2e-5, atol=1e-4)
+    lq, pm = oracle_c.log_qz(g["z"], g["mu"], g["logvar"], math.log(g["mu"].shape[0]))
+    close(lq, g["log_q_z_all"], **tol)
+    close(pm, g["log_q_z_prod_marg_all"], **tol)
+
+
+@pytest.mark.parametrize("case", ["k1", "k600", "k37_d64"])
+def test_c_oracle_iw(case):
+    from oracle import oracle_c
+    g = load_golden("iw_" + case)
+    z, lq, lp, iw = oracle_c.reparam_iw(g["mu"], g["logvar"], g["eps"], g["log_p_x_z"])
+    close(z, g["z"], rtol=1e-6, atol=1e-6)
+    close(lq, g["log_q_z_x"], atol=1e-4)
+    close(lp, g["log_p_z"], atol=1e-4)
+    close(iw, g["iw_ll"], atol=1e-4)
+
+
+@pytest.mark.parametrize("case", ["generic", "ragged", "d64"])
+def test_torch_eager_baseline(case):
+    import math
+    import torch
+    from oracle import torch_eager
+    g = load_golden("logqz_" + case)
+    lq, pm = torch_eager.log_qz(torch.from_numpy(g["mu"]), torch.from_numpy(g["logvar"]),
+                                torch.from_numpy(g["z"]), math.log(g["mu"].shape[0]), True, row_chunk=50)
+    close(lq.numpy(), g["log_q_z_all"], rtol=1e-5, atol=1e-4)
+    close(pm.numpy(), g["log_q_z_prod_marg_all"], rtol=1e-5, atol=1e-4)
