@@ -5,8 +5,9 @@
 // r runs over the REDUCED axis (posteriors for log q(z)), c over the KEPT axis (samples).  Operands
 // come from prep.hip.  Each wave owns 32*NCB kept elements for its whole life: their operand rows sit
 // in VGPRs as the B operand of v_mfma_f32_32x32x2_f32 (lane = column + 32*half).  The wave then streams
-// 32-row blocks of the reduced axis: one coalesced 1 KiB load per 4 MFMA steps brings the A operand
-// (fragment-major layout), the accumulators start from the row bias, DP chained MFMAs per 32x32 tile
+// 32-row blocks of the reduced axis through a private LDS ring filled by LDS-DMA (one 1 KiB piece per
+// 4 MFMA steps, fragment-major layout), the accumulators start from the row bias, DP chained MFMAs per
+// 32x32 tile
 // produce the base-2 log-densities, and the epilogue folds the 16 values a lane holds (16 reduced rows
 // of its own column) into that lane's running (max, sum).  The reduction axis lives on the MFMA ROW
 // index, i.e. in registers, so the logsumexp needs no cross-lane traffic until the very end, where
@@ -68,77 +69,138 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     int64_t b1 = b0 + blk_per_split;
     if (b1 > nblk) b1 = nblk;
 
-    const f32x4* afrag = reinterpret_cast<const f32x4*>(rfrag) + lane;
-    const f32x4* bfrag = reinterpret_cast<const f32x4*>(rbias) + h;
+    // ---- streaming of the reduced-axis operand through LDS -------------------------------------
+    // Every wave owns a private two-stage ring in LDS and fills it with LDS-DMA
+    // (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR staging).  The fragment-major
+    // global layout is lane-linear, which is exactly the image an LDS-DMA writes, and the later
+    // ds_read_b128 of lane l at offset 16*l is conflict-free.  Rings are private to a wave, so no
+    // workgroup barrier is needed: the issuing wave's own vmcnt wait orders DMA -> ds_read.
+    constexpr int CS = DP < 32 ? DP : 32;     // MFMA steps per ring stage ("chunk")
+    constexpr int CPB = DP / CS;              // chunks per 32-row block
+    constexpr int CQ = CS / 4;                // 1 KiB DMA pieces per chunk
+    constexpr int CHUNK_F = CS * 64;          // floats per chunk
+    constexpr int STAGE_F = CHUNK_F + 64;     // + one 256-B piece holding the block's 32 row biases
+    __shared__ __attribute__((aligned(16))) float lds[4 * 2 * STAGE_F];
+    float* const ring = lds + wave * (2 * STAGE_F);
 
-    f32x4 a_nxt[NQ];
-    f32x4 c_nxt[4];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto dma_chunk = [&](int64_t blk, int ch, int stage) {
+        const float* g = rfrag + (blk * (DP / 4) + ch * CQ) * 256 + lane * 4;
+        float* l = ring + stage * STAGE_F;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) a_nxt[q] = afrag[(b0 * NQ + q) * 64];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) c_nxt[g] = bfrag[b0 * 8 + 2 * g];
+        for (int q = 0; q < CQ; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(g + q * 256), (lptr_t)(l + q * 256), 16, 0, 0);
+        if (ch == 0)   // 64 lanes x 4 B: this block's 32 biases (+32 of the next block, unused)
+            __builtin_amdgcn_global_load_lds((gptr_t)(rbias + blk * 32 + lane), (lptr_t)(l + CHUNK_F), 4, 0, 0);
+    };
 
-    for (int64_t blk = b0; blk < b1; ++blk) {
-        f32x4 a_cur[NQ];
-        f32x4 c_cur[4];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) a_cur[q] = a_nxt[q];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) c_cur[g] = c_nxt[g];
-        // prefetch the next block (the last iteration re-reads its own block: harmless)
-        const int64_t nb = (blk + 1 < b1) ? blk + 1 : blk;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) a_nxt[q] = afrag[(nb * NQ + q) * 64];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) c_nxt[g] = bfrag[nb * 8 + 2 * g];
-
-        f32x16 acc[NCB];
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[cb][4 * g + e] = c_cur[g][e];
-
-#pragma unroll
-        for (int st = 0; st < DP; ++st) {
-            const float a = a_cur[st >> 2][st & 3];
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
-                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bz[cb][st], acc[cb], 0, 0, 0);
-        }
-
-        if (EXCL) {
-            // drop the pair (reduced row == kept column + offset): only blocks that can contain it
-            const int64_t row_lo = blk * 32;
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                const int64_t cbase = col0 + cb * 32 + excl_offset;
-                if (row_lo < cbase + 32 && row_lo + 32 > cbase) {
-                    const int64_t want = cbase + r - row_lo;   // row index inside the block
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (want == 8 * g + 4 * h + e) acc[cb][4 * g + e] = -INFINITY;
-                }
-            }
-        }
-
+    auto mask_diag = [&](f32x16 (&acc)[NCB], int64_t blk) {
+        // drop the pair (reduced row == kept column + offset): only blocks that can contain it
+        const int64_t row_lo = blk * 32;
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
-            float t = acc[cb][0];
+            const int64_t cbase = col0 + cb * 32 + excl_offset;
+            if (row_lo < cbase + 32 && row_lo + 32 > cbase) {
+                const int64_t want = cbase + r - row_lo;   // row index inside the block
 #pragma unroll
-            for (int e = 1; e < 16; ++e) t = fmaxf(t, acc[cb][e]);
-            if (__any(t > m[cb] + LSE_THR)) {
-                const float mn = (t > m[cb] + LSE_THR) ? t : m[cb];
-                s[cb] *= lvae_exp2(m[cb] - mn);
-                m[cb] = mn;
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (want == 8 * g + 4 * h + e) acc[cb][4 * g + e] = -INFINITY;
             }
+        }
+    };
+    // Epilogue of one 32x32 tile, cut into EPI_SLICES slices so that it can be spread over the MFMA
+    // steps of the next block.  Slice 0: tile max + lazy rescale; slices 1..4: 4 exponentials each.
+    constexpr int EPI_SLICES = 5;
+    auto epi_slice = [&](const f32x16 (&prev)[NCB], int cb, int sl) {
+        if (sl == 0) {
+            float t = prev[cb][0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) t = fmaxf(t, prev[cb][e]);
+            const float mn = (t > m[cb] + LSE_THR) ? t : m[cb];
+            s[cb] *= lvae_exp2(m[cb] - mn);
+            m[cb] = mn;
+        } else {
             float add = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) add += lvae_exp2(acc[cb][e] - m[cb]);
+            for (int e = 4 * (sl - 1); e < 4 * sl; ++e) add += lvae_exp2(prev[cb][e] - m[cb]);
             s[cb] += add;
+        }
+    };
+    constexpr int EPI_TOTAL = EPI_SLICES * NCB;
+    constexpr int EPI_GAP = DP / EPI_TOTAL > 0 ? DP / EPI_TOTAL : 1;
+
+    // One block: wait for its chunks, keep the ring one chunk ahead, run the DP*NCB MFMAs into `acc`
+    // while the epilogue of `prev` (the block before) issues in their shadow.
+    int64_t t_lin = 0;                                     // chunks consumed so far by this wave
+    const int64_t t_end = (b1 - b0) * CPB;
+    auto run_block = [&](f32x16 (&acc)[NCB], const f32x16 (&prev)[NCB], int64_t blk, bool with_epi) {
+#pragma unroll
+        for (int ch = 0; ch < CPB; ++ch) {
+            const int stage = (int)(t_lin & 1);
+            // chunk t_lin was issued one chunk ago and is the only DMA in flight
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (t_lin + 1 < t_end) {
+                const int nch = (ch + 1) % CPB;
+                dma_chunk(nch == 0 ? blk + 1 : blk, nch, stage ^ 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float* st_base = ring + stage * STAGE_F;
+            if (ch == 0) {
+                const f32x4* bl = reinterpret_cast<const f32x4*>(st_base + CHUNK_F) + h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 c = bl[2 * g];
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[cb][4 * g + e] = c[e];
+                }
+            }
+            const f32x4* al = reinterpret_cast<const f32x4*>(st_base) + lane;
+#pragma unroll
+            for (int q = 0; q < CQ; ++q) {
+                const f32x4 a4 = al[q * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int st = ch * CS + q * 4 + e;
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], bz[cb][st], acc[cb], 0, 0, 0);
+                    if (with_epi && st % EPI_GAP == 0 && st / EPI_GAP < EPI_TOTAL) {
+                        const int k = st / EPI_GAP;
+                        epi_slice(prev, k / EPI_SLICES, k % EPI_SLICES);
+                    }
+                }
+            }
+            ++t_lin;
+        }
+        if (EXCL) mask_diag(acc, blk);
+    };
+
+    f32x16 accA[NCB], accB[NCB];
+    if (b0 < b1) {
+        dma_chunk(b0, 0, 0);
+        run_block(accA, accB, b0, false);
+        int64_t blk = b0 + 1;
+        // two blocks per trip so the accumulator sets swap roles without register copies
+        for (; blk + 1 < b1; blk += 2) {
+            run_block(accB, accA, blk, true);
+            run_block(accA, accB, blk + 1, true);
+        }
+        if (blk < b1) {
+            run_block(accB, accA, blk, true);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int sl = 0; sl < EPI_SLICES; ++sl) epi_slice(accB, cb, sl);
+        } else {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int sl = 0; sl < EPI_SLICES; ++sl) epi_slice(accA, cb, sl);
         }
     }
 
@@ -179,7 +241,7 @@ int lvae_launch_pair_lse_mfma(const PairPlan& p, const float* rfrag, const float
         return lvae_set_error(LVAE_ERR_INVALID, "pair plan: cpad %lld not a multiple of the tile",
                               (long long)p.cpad);
     switch (p.DP) {
-        case 16: return launch_t<16, 4, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, st);
+        case 16: return launch_t<16, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, st);
         case 32: return launch_t<32, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, st);
         case 64: return launch_t<64, 1, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, st);
         case 128: return launch_t<128, 1, 1>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, st);

@@ -1,6 +1,7 @@
 // Host-side plan for one "pair log-density + logsumexp" job: tile shapes, grid split and the
 // layout of the caller-provided workspace.  Shared by the MFMA path, the direct path and the API.
 #pragma once
+#include <stdlib.h>
 #include "lvae_common.h"
 
 // Lives at the start of the workspace; zeroed (hipMemsetAsync) at the start of every call.
@@ -33,13 +34,15 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
     PairPlan p{};
     p.R = R; p.C = C; p.D = D; p.with_pm = with_pm;
     p.DP = lvae_pad_dim(D);
-    p.NCB = (p.DP == 16) ? 4 : (p.DP == 32 ? 2 : 1);
+    p.NCB = (p.DP == 16 || p.DP == 32) ? 2 : 1;
     p.nblk = lvae_ceil_div(R, 32);
     const int64_t wg_cols = p.DP ? 4 * 32 * p.NCB : 256;
     p.cpad = lvae_round_up(C, wg_cols < 256 ? 256 : wg_cols);
     // MFMA grid: aim at two waves per SIMD on 256 CUs (2048 waves), never more splits than blocks
     const int64_t col_waves = p.DP ? p.cpad / (32 * p.NCB) : 1;
-    int64_t ns = lvae_ceil_div(2048, col_waves);
+    const char* tw_env = getenv("LVAE_TARGET_WAVES");
+    const int64_t target_waves = tw_env ? atoll(tw_env) : 2048;
+    int64_t ns = lvae_ceil_div(target_waves, col_waves);
     if (ns > p.nblk) ns = p.nblk;
     if (ns < 1) ns = 1;
     if (ns > 64) ns = 64;
@@ -58,7 +61,7 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
     size_t o = 0;
     p.off_hdr = o;      o = lvae_align256(o + sizeof(PairHeader));
     p.off_rfrag = o;    o = lvae_align256(o + (size_t)p.nblk * (p.DP ? p.DP : 0) * 64 * sizeof(float));
-    p.off_rbias = o;    o = lvae_align256(o + (size_t)p.nblk * 32 * sizeof(float));
+    p.off_rbias = o;    o = lvae_align256(o + ((size_t)p.nblk * 32 + 64) * sizeof(float));
     p.off_cop = o;      o = lvae_align256(o + (size_t)p.cpad * 2 * p.DP * sizeof(float));
     p.off_colbias = o;  o = lvae_align256(o + (size_t)p.cpad * sizeof(float));
     p.off_partial = o;  o = lvae_align256(o + (size_t)p.nsplit * p.cpad * 2 * sizeof(float));
