@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblvae.so")
+LIB_PATH = os.environ.get("LVAE_LIB", os.path.join(_HERE, "liblvae.so"))
 
 SPREAD_LOGVAR, SPREAD_VAR = 0, 1
 PATH_AUTO, PATH_MFMA, PATH_DIRECT = 0, 1, 2

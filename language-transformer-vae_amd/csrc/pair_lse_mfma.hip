@@ -5,8 +5,8 @@
 // r runs over the REDUCED axis (posteriors for log q(z)), c over the KEPT axis (samples).  Operands
 // come from prep.hip.  Each wave owns 32*NCB kept elements for its whole life: their operand rows sit
 // in VGPRs as the B operand of v_mfma_f32_32x32x2_f32 (lane = column + 32*half).  The wave then streams
-// 32-row blocks of the reduced axis through a private LDS ring filled by LDS-DMA (one 1 KiB piece per
-// 4 MFMA steps, fragment-major layout), the accumulators start from the row bias, DP chained MFMAs per
+// 32-row blocks of the reduced axis through an LDS ring shared by the workgroup's four waves and filled
+// by LDS-DMA (one 1 KiB piece per 4 MFMA steps, fragment-major layout), the accumulators start from the row bias, DP chained MFMAs per
 // 32x32 tile
 // produce the base-2 log-densities, and the epilogue folds the 16 values a lane holds (16 reduced rows
 // of its own column) into that lane's running (max, sum).  The reduction axis lives on the MFMA ROW
@@ -22,6 +22,23 @@
 #include "pair_plan.h"
 
 #define LSE_THR 8.0f
+
+// s_waitcnt vmcnt(n) for a small n known after unrolling
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
 #define LSE_MINIT (-1.0e30f)
 
 template <int DP, int NCB, int WPS, bool EXCL>
@@ -70,18 +87,26 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     if (b1 > nblk) b1 = nblk;
 
     // ---- streaming of the reduced-axis operand through LDS -------------------------------------
-    // Every wave owns a private two-stage ring in LDS and fills it with LDS-DMA
-    // (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR staging).  The fragment-major
-    // global layout is lane-linear, which is exactly the image an LDS-DMA writes, and the later
-    // ds_read_b128 of lane l at offset 16*l is conflict-free.  Rings are private to a wave, so no
-    // workgroup barrier is needed: the issuing wave's own vmcnt wait orders DMA -> ds_read.
+    // The four waves of a workgroup sweep the same reduced-axis blocks (each for its own columns), so
+    // they share one three-stage ring in LDS and fill it together with LDS-DMA
+    // (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR staging; each wave brings a quarter
+    // of every chunk).  The fragment-major global layout is lane-linear, which is exactly the image an
+    // LDS-DMA writes, and the later ds_read_b128 of lane l at offset 16*l is conflict-free.
+    // One barrier per chunk: before it every wave drains its own DMAs (vmcnt) of the chunk issued at
+    // the top of this one (two chunks ahead of the one being consumed); after it that chunk is
+    // complete for everybody and the stage just consumed may be overwritten.
     constexpr int CS = DP < 32 ? DP : 32;     // MFMA steps per ring stage ("chunk")
     constexpr int CPB = DP / CS;              // chunks per 32-row block
     constexpr int CQ = CS / 4;                // 1 KiB DMA pieces per chunk
     constexpr int CHUNK_F = CS * 64;          // floats per chunk
     constexpr int STAGE_F = CHUNK_F + 64;     // + one 256-B piece holding the block's 32 row biases
-    __shared__ __attribute__((aligned(16))) float lds[4 * 2 * STAGE_F];
-    float* const ring = lds + wave * (2 * STAGE_F);
+#ifndef LVAE_PF
+#define LVAE_PF 3
+#endif
+    constexpr int PF = LVAE_PF;               // chunks the DMA runs ahead of the MFMAs
+    constexpr int NST = PF + 1;
+    __shared__ __attribute__((aligned(16))) float ring[NST * STAGE_F];
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -89,10 +114,20 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
         const float* g = rfrag + (blk * (DP / 4) + ch * CQ) * 256 + lane * 4;
         float* l = ring + stage * STAGE_F;
 #pragma unroll
-        for (int q = 0; q < CQ; ++q)
+        for (int q0 = 0; q0 < CQ; q0 += 4) {
+            const int q = q0 + wave_u;
             __builtin_amdgcn_global_load_lds((gptr_t)(g + q * 256), (lptr_t)(l + q * 256), 16, 0, 0);
-        if (ch == 0)   // 64 lanes x 4 B: this block's 32 biases (+32 of the next block, unused)
+        }
+        if (ch == 0)   // 64 lanes x 4 B: this block's 32 biases (+32 of the next block, unused); every wave
+                       // writes the same bytes so that all waves have the same DMA count per chunk
             __builtin_amdgcn_global_load_lds((gptr_t)(rbias + blk * 32 + lane), (lptr_t)(l + CHUNK_F), 4, 0, 0);
+    };
+    // chunk index t (counted from this workgroup's first block) -> (block, chunk-in-block), clamped to
+    // the last chunk of the range so that running ahead past the end is a harmless re-read
+    const int64_t t_end = (b1 - b0) * CPB;
+    auto dma_linear = [&](int64_t t) {
+        if (t >= t_end) t = t_end - 1;
+        dma_chunk(b0 + t / CPB, (int)(t % CPB), (int)(t % NST));
     };
 
     auto mask_diag = [&](f32x16 (&acc)[NCB], int64_t blk) {
@@ -111,78 +146,131 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
             }
         }
     };
-    // Epilogue of one 32x32 tile, cut into EPI_SLICES slices so that it can be spread over the MFMA
-    // steps of the next block.  Slice 0: tile max + lazy rescale; slices 1..4: 4 exponentials each.
-    constexpr int EPI_SLICES = 5;
-    auto epi_slice = [&](const f32x16 (&prev)[NCB], int cb, int sl) {
-        if (sl == 0) {
+
+    // Epilogue of one 32x32 tile, cut into EPI_MS micro-slices of <= ~10 VALU instructions so that
+    // each one issues in the shadow of one MFMA of the NEXT block (64 cycles of matrix-pipe time):
+    //   0: max of elements 0..7        1: max of 8..15, lazy rescale of the running (max, sum)
+    //   2..9: two exponentials each, added to the running sum.
+    constexpr int EPI_MS = 10;
+    float tmax[NCB];
+    auto epi_micro = [&](const f32x16 (&prev)[NCB], int cb, int ms) {
+        if (ms == 0) {
             float t = prev[cb][0];
 #pragma unroll
-            for (int e = 1; e < 16; ++e) t = fmaxf(t, prev[cb][e]);
+            for (int e = 1; e < 8; ++e) t = fmaxf(t, prev[cb][e]);
+            tmax[cb] = t;
+        } else if (ms == 1) {
+            float t = tmax[cb];
+#pragma unroll
+            for (int e = 8; e < 16; ++e) t = fmaxf(t, prev[cb][e]);
             const float mn = (t > m[cb] + LSE_THR) ? t : m[cb];
             s[cb] *= lvae_exp2(m[cb] - mn);
             m[cb] = mn;
         } else {
-            float add = 0.f;
-#pragma unroll
-            for (int e = 4 * (sl - 1); e < 4 * sl; ++e) add += lvae_exp2(prev[cb][e] - m[cb]);
-            s[cb] += add;
+            const int e = 2 * (ms - 2);
+#if defined(LVAE_DBG_EPI_ADDONLY)
+            s[cb] += prev[cb][e] + prev[cb][e + 1];
+#elif defined(LVAE_DBG_EPI_NOSUB)
+            s[cb] += lvae_exp2(prev[cb][e]) + lvae_exp2(prev[cb][e + 1]);
+#else
+            s[cb] += lvae_exp2(prev[cb][e] - m[cb]) + lvae_exp2(prev[cb][e + 1] - m[cb]);
+#endif
         }
     };
-    constexpr int EPI_TOTAL = EPI_SLICES * NCB;
-    constexpr int EPI_GAP = DP / EPI_TOTAL > 0 ? DP / EPI_TOTAL : 1;
+    constexpr int SLOTS = DP * NCB;                    // MFMAs per block
+    constexpr int MS_TOTAL = EPI_MS * NCB;             // micro-slices per block
+    constexpr int MS_STRIDE = SLOTS / MS_TOTAL > 0 ? SLOTS / MS_TOTAL : 1;
+    static_assert(MS_TOTAL <= SLOTS, "epilogue does not fit under one block of MFMAs");
 
-    // One block: wait for its chunks, keep the ring one chunk ahead, run the DP*NCB MFMAs into `acc`
-    // while the epilogue of `prev` (the block before) issues in their shadow.
+    // Values carried from the tail of one chunk into the next: the first 1 KiB piece of the next chunk
+    // and (at a block boundary) the next block's row biases, both already read from LDS.
+    f32x4 a_pre;
+    f32x16 c_pre;
+    auto read_piece = [&](int stage, int q) -> f32x4 {
+        return reinterpret_cast<const f32x4*>(ring + stage * STAGE_F)[q * 64 + lane];
+    };
+    auto read_bias = [&](int stage) {
+        const f32x4* bl = reinterpret_cast<const f32x4*>(ring + stage * STAGE_F + CHUNK_F) + h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 c = bl[2 * g];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c_pre[4 * g + e] = c[e];
+        }
+    };
+
+    // One block: keep the ring one chunk ahead, run the DP*NCB MFMAs into `acc` (first step takes the
+    // row biases as its C operand) while the epilogue of `prev` issues in their shadow.  Everything is
+    // pinned in program order (sched_barrier) so the compiler cannot bunch the epilogue up.
     int64_t t_lin = 0;                                     // chunks consumed so far by this wave
-    const int64_t t_end = (b1 - b0) * CPB;
     auto run_block = [&](f32x16 (&acc)[NCB], const f32x16 (&prev)[NCB], int64_t blk, bool with_epi) {
+        const f32x16 cv = c_pre;
 #pragma unroll
         for (int ch = 0; ch < CPB; ++ch) {
-            const int stage = (int)(t_lin & 1);
-            // chunk t_lin was issued one chunk ago and is the only DMA in flight
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (t_lin + 1 < t_end) {
-                const int nch = (ch + 1) % CPB;
-                dma_chunk(nch == 0 ? blk + 1 : blk, nch, stage ^ 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const float* st_base = ring + stage * STAGE_F;
-            if (ch == 0) {
-                const f32x4* bl = reinterpret_cast<const f32x4*>(st_base + CHUNK_F) + h;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 c = bl[2 * g];
-#pragma unroll
-                    for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[cb][4 * g + e] = c[e];
-                }
-            }
-            const f32x4* al = reinterpret_cast<const f32x4*>(st_base) + lane;
+            const int stage = (int)(t_lin % NST);
+            const int stage_next = (int)((t_lin + 1) % NST);
+#ifndef LVAE_DBG_NODMA
+            dma_linear(t_lin + PF);    // into the stage consumed one chunk ago (freed by the last barrier)
+#endif
+            f32x4 a4[2];
+            a4[0] = a_pre;
 #pragma unroll
             for (int q = 0; q < CQ; ++q) {
-                const f32x4 a4 = al[q * 64];
+                if (q + 1 < CQ) {
+                    a4[(q + 1) & 1] = read_piece(stage, q + 1);
+                } else {
+                    // chunk t_lin+1 was certified complete by the barrier that ended chunk t_lin-1
+                    a_pre = read_piece(stage_next, 0);
+                    if (ch == CPB - 1) read_bias(stage_next);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int st = ch * CS + q * 4 + e;
 #pragma unroll
-                    for (int cb = 0; cb < NCB; ++cb)
-                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], bz[cb][st], acc[cb], 0, 0, 0);
-                    if (with_epi && st % EPI_GAP == 0 && st / EPI_GAP < EPI_TOTAL) {
-                        const int k = st / EPI_GAP;
-                        epi_slice(prev, k / EPI_SLICES, k % EPI_SLICES);
+                    for (int cb = 0; cb < NCB; ++cb) {
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q & 1][e], bz[cb][st],
+                                                                       st == 0 ? cv : acc[cb], 0, 0, 0);
+                        const int u = st * NCB + cb;
+#ifndef LVAE_DBG_NOEPI
+                        if (with_epi && u % MS_STRIDE == (MS_STRIDE > 1 ? 1 : 0) && u / MS_STRIDE < MS_TOTAL) {
+                            const int k = u / MS_STRIDE;
+                            epi_micro(prev, k / EPI_MS, k % EPI_MS);
+                        }
+#endif
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
+            // my pieces of chunk t_lin+2 have landed; after the barrier everybody's have, and
+            // everybody is done reading chunk t_lin's stage
+            // (chunks t_lin+3 .. t_lin+PF, issued later, may stay in flight: counted wait)
+            {
+                constexpr int per_chunk = CQ / 4;
+                int left = 0;
+#pragma unroll
+                for (int k = 3; k <= PF; ++k) left += per_chunk + (((ch + k) % CPB) == 0 ? 1 : 0);
+                wait_vmcnt(left);
+            }
+            __builtin_amdgcn_s_barrier();
             ++t_lin;
         }
         if (EXCL) mask_diag(acc, blk);
     };
+    auto drain = [&](const f32x16 (&prev)[NCB]) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int ms = 0; ms < EPI_MS; ++ms) epi_micro(prev, cb, ms);
+    };
 
     f32x16 accA[NCB], accB[NCB];
     if (b0 < b1) {
-        dma_chunk(b0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < PF; ++k) dma_linear(k);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        a_pre = read_piece(0, 0);
+        read_bias(0);
         run_block(accA, accB, b0, false);
         int64_t blk = b0 + 1;
         // two blocks per trip so the accumulator sets swap roles without register copies
@@ -192,15 +280,9 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
         }
         if (blk < b1) {
             run_block(accB, accA, blk, true);
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                for (int sl = 0; sl < EPI_SLICES; ++sl) epi_slice(accB, cb, sl);
+            drain(accB);
         } else {
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                for (int sl = 0; sl < EPI_SLICES; ++sl) epi_slice(accA, cb, sl);
+            drain(accA);
         }
     }
 
