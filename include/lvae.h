@@ -103,6 +103,14 @@ int lvae_reparam_iw_f32(const float* mu, const float* logvar, const float* eps, 
 int lvae_iw_lse_f32(const float* log_p_x_z, const float* log_p_z, const float* log_q_z_x, int64_t B,
                     int64_t K, float* out, void* stream);
 
+/* Fused tail of the aggregate-posterior statistics for samples z_i drawn from posterior i (M rows):
+ * evaluates log p(z_i) and log q(z_i|x_i) on the fly and returns, in device memory,
+ *   sums[5] = { sum log_qz, sum log_qz_prod_marg, sum log p(z), sum log q(z|x), M }   (float64)
+ * i.e. the four means that assemble_loss turns into MI / TC / dim-KL / marginal-KL
+ * (loss_and_optimisation.py:816-824).  log_qz / log_qz_prod_marg [M] may be NULL (sum = 0). */
+int lvae_latent_sums_f32(const float* z, const float* mu, const float* logvar, const float* log_qz,
+                         const float* log_qz_prod_marg, int64_t M, int D, double* sums, void* stream);
+
 /* Deterministic reduction to one float64 in device memory: mode 0: scale*sum(x), mode 1:
  * scale*sum(exp(x)).  Used for the `.mean()` the reference applies to per-sample vectors
  * (loss_and_optimisation.py:108,:217-219).  Workspace: LVAE_REDUCE_WS_BYTES. */

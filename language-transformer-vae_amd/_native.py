@@ -40,6 +40,8 @@ _SIGNATURES = {
     "lvae_iw_lse_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _i64, _c_f32p, ctypes.c_void_p]),
     "lvae_reduce_f32": (_int, [_c_f32p, _i64, _int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
                                _i64, ctypes.c_void_p]),
+    "lvae_latent_sums_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, ctypes.c_void_p,
+                                    ctypes.c_void_p]),
     "lvae_profile_begin": (_int, [_int]),
     "lvae_profile_end": (_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_int)]),
 }

@@ -37,6 +37,9 @@ int lvae_launch_sample_ll_elem(const float* mu, const float* logvar, const float
 int lvae_launch_iw_lse(const float* a, const float* b, const float* c, int64_t B, int64_t K, float* out,
                        hipStream_t st);
 
+int lvae_launch_latent_sums(const float* z, const float* mu, const float* logvar, const float* log_qz,
+                            const float* log_qz_pm, int64_t M, int D, double* sums, hipStream_t st);
+
 // ---- error text, per calling thread --------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
@@ -340,4 +343,12 @@ extern "C" int lvae_reduce_f32(const float* x, int64_t n, int mode, double scale
     int rc = check_ws(ws, ws_bytes, LVAE_REDUCE_WS_BYTES);
     if (rc) return rc;
     return lvae_launch_reduce(mode, x, n, scale, out, (double*)ws, (hipStream_t)stream);
+}
+
+extern "C" int lvae_latent_sums_f32(const float* z, const float* mu, const float* logvar,
+                                    const float* log_qz, const float* log_qz_prod_marg, int64_t M, int D,
+                                    double* sums, void* stream) {
+    LVAE_CHECK_ARG(z && mu && logvar && sums, "z, mu, logvar and sums must be non-NULL");
+    LVAE_CHECK_ARG(M >= 1 && D >= 1, "need M >= 1 and D >= 1");
+    return lvae_launch_latent_sums(z, mu, logvar, log_qz, log_qz_prod_marg, M, D, sums, (hipStream_t)stream);
 }

@@ -15,75 +15,127 @@
 // 16-byte load per chunk is then a single contiguous 1 KiB read.
 #include "pair_plan.h"
 
-__global__ void colsum_kernel(const float* __restrict__ mu, int64_t n, int D, PairHeader* hdr,
-                              int rows_per_block) {
-    const int d = threadIdx.x;
-    if (d >= D) return;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    int64_t r1 = r0 + rows_per_block;
+// Per-dimension sum of the posterior means.  Each block sweeps a contiguous slab of rows with fully
+// coalesced loads; a thread's dimension is fixed when 256 % D == 0 (register accumulation), otherwise
+// the slab is accumulated through LDS atomics.
+#define COLSUM_ROWS 128
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ mu, int64_t n, int D,
+                                                     PairHeader* hdr) {
+    __shared__ float sm[256];
+    const int64_t r0 = (int64_t)blockIdx.x * COLSUM_ROWS;
+    int64_t r1 = r0 + COLSUM_ROWS;
     if (r1 > n) r1 = n;
-    double acc = 0.0;
-    for (int64_t r = r0; r < r1; ++r) acc += (double)mu[r * D + d];
-    atomicAdd(&hdr->colsum[d], acc);
+    const int64_t e0 = r0 * D, e1 = r1 * D;
+    if (D <= 256 && 256 % D == 0) {
+        float acc = 0.f;
+        for (int64_t i = e0 + threadIdx.x; i < e1; i += 256) acc += mu[i];
+        sm[threadIdx.x] = acc;
+        __syncthreads();
+        if (threadIdx.x < D) {
+            double t = 0.0;
+            for (int k = threadIdx.x; k < 256; k += D) t += (double)sm[k];
+            atomicAdd(&hdr->colsum[threadIdx.x], t);
+        }
+    } else {
+        for (int d0 = 0; d0 < D; d0 += 256) {      // D > 256 or odd D: LDS atomics, 256 dims at a time
+            sm[threadIdx.x] = 0.f;
+            __syncthreads();
+            for (int64_t i = e0 + threadIdx.x; i < e1; i += 256) {
+                const int d = (int)(i % D);
+                if (d >= d0 && d < d0 + 256) atomicAdd(&sm[d - d0], mu[i]);
+            }
+            __syncthreads();
+            if (d0 + threadIdx.x < D && d0 + threadIdx.x < 128)
+                atomicAdd(&hdr->colsum[d0 + threadIdx.x], (double)sm[threadIdx.x]);
+            __syncthreads();
+        }
+    }
 }
 
-// One thread per (padded) row.  GAUSS rows come from (mu, spread), SAMPLE rows from z.
-// FRAG selects the fragment-major reduced-axis layout, otherwise row-major [row][2*DP] (kept axis).
+// One thread per (row, 4 consecutive dimensions); a block covers 32 rows (= one fragment block).
+// GAUSS rows come from (mu, spread), SAMPLE rows from z.  FRAG selects the fragment-major
+// reduced-axis layout (threads ordered row-fastest so that each wave stores whole 512-B runs),
+// otherwise row-major [row][2*DP] for the kept axis (threads ordered dimension-fastest).
 template <bool GAUSS, bool FRAG>
-__global__ void prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ spread,
-                                    int spread_kind, int64_t n, int64_t npad, int D, int DP,
-                                    PairHeader* hdr, double inv_ngauss, float* __restrict__ out,
-                                    float* __restrict__ bias, float* __restrict__ dparams, int DC) {
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= npad) return;
+__global__ void __launch_bounds__(1024)
+prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ spread, int spread_kind,
+                    int64_t n, int64_t npad, int D, int DP, PairHeader* hdr, double inv_ngauss,
+                    float* __restrict__ out, float* __restrict__ bias, float* __restrict__ dparams,
+                    int DC) {
+    __shared__ float sm_shift[128];
+    __shared__ float sm_c[1024];
+    __shared__ float sm_k[1024];
+    const int NQ = DP >> 2;
+    const int tid = threadIdx.x;
+    if (tid < DP) sm_shift[tid] = tid < D ? (float)(hdr->colsum[tid] * inv_ngauss) : 0.f;
+    __syncthreads();
+    const int r = FRAG ? (tid & 31) : (tid / NQ);
+    const int q = FRAG ? (tid >> 5) : (tid % NQ);
+    const int64_t blk = blockIdx.x;
+    const int64_t row = blk * 32 + r;
     const bool valid = row < n;
-    const int64_t blk = row >> 5;
-    const int r = (int)(row & 31);
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
     float csum = 0.f, cond = 0.f;
-    for (int d = 0; d < DP; ++d) {
-        float v0 = 0.f, v1 = 0.f;
-        if (valid && d < D) {
-            const float shift = (float)(hdr->colsum[d] * inv_ngauss);
-            const float xv = x[row * D + d];
-            const float xs = xv - shift;
-            if (GAUSS) {
-                const float sp = spread[row * D + d];
-                const float logvar = spread_kind == LVAE_SPREAD_VAR ? logf(sp) : sp;
-                const float p = spread_kind == LVAE_SPREAD_VAR ? 1.0f / sp : expf(-sp);
-                v0 = -0.5f * LVAE_LOG2E * p;
-                v1 = LVAE_LOG2E * xs * p;
-                csum += xs * xs * p + logvar + LVAE_LOG_2PI;
-                const float t = 2.0f * fabsf(xs) * sqrtf(p) + 3.0f;
-                cond += 0.5f * t * t;
-                if (dparams) {
-                    dparams[(row * 3 + 0) * DC + d] = xv;
-                    dparams[(row * 3 + 1) * DC + d] = sqrtf(0.5f * LVAE_LOG2E * p);
-                    dparams[(row * 3 + 2) * DC + d] = -0.5f * LVAE_LOG2E * (logvar + LVAE_LOG_2PI);
+    if (valid) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int d = 4 * q + e;
+            if (d < D) {
+                const float xv = x[row * D + d];
+                const float xs = xv - sm_shift[d];
+                if (GAUSS) {
+                    const float sp = spread[row * D + d];
+                    const float logvar = spread_kind == LVAE_SPREAD_VAR ? logf(sp) : sp;
+                    const float p = spread_kind == LVAE_SPREAD_VAR ? 1.0f / sp : expf(-sp);
+                    v0[e] = -0.5f * LVAE_LOG2E * p;
+                    v1[e] = LVAE_LOG2E * xs * p;
+                    csum += xs * xs * p + logvar + LVAE_LOG_2PI;
+                    const float t = 2.0f * fabsf(xs) * sqrtf(p) + 3.0f;
+                    cond += 0.5f * t * t;
+                    if (dparams) {
+                        dparams[(row * 3 + 0) * DC + d] = xv;
+                        dparams[(row * 3 + 1) * DC + d] = sqrtf(0.5f * LVAE_LOG2E * p);
+                        dparams[(row * 3 + 2) * DC + d] = -0.5f * LVAE_LOG2E * (logvar + LVAE_LOG_2PI);
+                    }
+                } else {
+                    v0[e] = xs * xs;
+                    v1[e] = xs;
                 }
-            } else {
-                v0 = xs * xs;
-                v1 = xs;
+            } else if (GAUSS && dparams && d < DC) {
+                dparams[(row * 3 + 0) * DC + d] = 0.f;
+                dparams[(row * 3 + 1) * DC + d] = 0.f;
+                dparams[(row * 3 + 2) * DC + d] = 0.f;
             }
-        } else if (GAUSS && dparams && valid && d < DC) {
-            dparams[(row * 3 + 0) * DC + d] = 0.f;
-            dparams[(row * 3 + 1) * DC + d] = 0.f;
-            dparams[(row * 3 + 2) * DC + d] = 0.f;
         }
+    }
+    if (row < npad) {
         if (FRAG) {
-            float* o = out + blk * (int64_t)DP * 64 + (d >> 2) * 256 + (d & 3);
-            o[r * 4] = v0;
-            o[(32 + r) * 4] = v1;
+            f32x4* o = reinterpret_cast<f32x4*>(out + blk * (int64_t)DP * 64 + q * 256);
+            o[r] = v0;
+            o[32 + r] = v1;
         } else {
-            out[row * 2 * DP + d] = v0;
-            out[row * 2 * DP + DP + d] = v1;
+            *reinterpret_cast<f32x4*>(out + row * 2 * DP + 4 * q) = v0;
+            *reinterpret_cast<f32x4*>(out + row * 2 * DP + DP + 4 * q) = v1;
         }
     }
-    if (bias) {
-        float b = GAUSS ? -0.5f * LVAE_LOG2E * csum : 0.f;
-        if (!valid) b = FRAG ? -INFINITY : 0.f;
-        bias[row] = b;
+    if (bias || GAUSS) {
+        sm_c[r * NQ + q] = csum;
+        sm_k[r * NQ + q] = cond;
+        __syncthreads();
+        if (q == 0 && row < npad) {
+            float c = 0.f, k = 0.f;
+            for (int j = 0; j < NQ; ++j) {
+                c += sm_c[r * NQ + j];
+                k += sm_k[r * NQ + j];
+            }
+            if (bias) {
+                float b = GAUSS ? -0.5f * LVAE_LOG2E * c : 0.f;
+                if (!valid) b = FRAG ? -INFINITY : 0.f;
+                bias[row] = b;
+            }
+            if (GAUSS && valid) atomicMax(&hdr->cond_bits, __float_as_uint(k));
+        }
     }
-    if (GAUSS && valid) atomicMax(&hdr->cond_bits, __float_as_uint(cond));
 }
 
 // Direct-path parameters only (used when the MFMA path is not available for this D).
@@ -159,11 +211,9 @@ __global__ void finalize_pm_kernel(const float2* __restrict__ partial, int nspli
 
 // ---- host launchers ----------------------------------------------------------------------------
 int lvae_launch_colsum(const float* mu, int64_t n, int D, PairHeader* hdr, hipStream_t st) {
-    const int rows_per_block = 256;
-    const int threads = (int)lvae_round_up(D, 64);
-    const int64_t blocks = lvae_ceil_div(n, rows_per_block);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(threads), 0, st, mu, n, D, hdr,
-                       rows_per_block);
+    if (D > 128) return lvae_set_error(LVAE_ERR_INVALID, "colsum: D > 128");
+    const int64_t blocks = lvae_ceil_div(n, COLSUM_ROWS);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, mu, n, D, hdr);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }
@@ -171,8 +221,8 @@ int lvae_launch_colsum(const float* mu, int64_t n, int D, PairHeader* hdr, hipSt
 int lvae_launch_prep(bool gauss, bool frag, const float* x, const float* spread, int spread_kind,
                      int64_t n, int64_t npad, int D, int DP, PairHeader* hdr, int64_t ngauss,
                      float* out, float* bias, float* dparams, int DC, hipStream_t st) {
-    const int threads = 128;
-    const dim3 grid((unsigned)lvae_ceil_div(npad, threads));
+    const int threads = 32 * (DP / 4);
+    const dim3 grid((unsigned)lvae_ceil_div(npad, 32));
     const double inv = 1.0 / (double)ngauss;
 #define LVAE_PREP(G, F)                                                                          \
     hipLaunchKernelGGL((prep_operand_kernel<G, F>), grid, dim3(threads), 0, st, x, spread,        \

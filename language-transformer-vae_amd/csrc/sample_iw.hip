@@ -177,6 +177,44 @@ iw_lse_kernel(const float* __restrict__ log_p_x_z, const float* __restrict__ log
     if (lane == 0) out[b] = (float)((double)mx + log(s) - log((double)K));
 }
 
+// Densities only (no per-sentence reduction): rows = B*K flattened, G lanes per row, grid-stride.
+__global__ void __launch_bounds__(256)
+sample_ll_rows_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                      const float* __restrict__ z, int64_t rows, int64_t K, int D, int G,
+                      float* __restrict__ log_q_z_x, float* __restrict__ log_p_z) {
+    const int gl = threadIdx.x % G;
+    const int64_t rows_per_pass = (int64_t)gridDim.x * (256 / G);
+    const bool have_post = mu != nullptr;
+    for (int64_t base = (int64_t)blockIdx.x * (256 / G); base < rows; base += rows_per_pass) {
+        const int64_t row = base + threadIdx.x / G;
+        const bool ok = row < rows;
+        float lq = 0.f, lp = 0.f;
+        if (ok) {
+            const f32x4 zz = *reinterpret_cast<const f32x4*>(z + row * D + 4 * gl);
+            f32x4 mm = {0.f, 0.f, 0.f, 0.f}, lv = mm;
+            if (have_post) {
+                const int64_t b = row / K;
+                mm = *reinterpret_cast<const f32x4*>(mu + b * D + 4 * gl);
+                lv = *reinterpret_cast<const f32x4*>(logvar + b * D + 4 * gl);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (have_post) {
+                    const float df = zz[e] - mm[e];
+                    lq += -0.5f * (lv[e] + LVAE_LOG_2PI + __fdiv_rn(df * df, expf(lv[e])));
+                }
+                lp += -0.5f * (LVAE_LOG_2PI + zz[e] * zz[e]);
+            }
+        }
+        lq = group_sum(lq, G);
+        lp = group_sum(lp, G);
+        if (ok && gl == 0) {
+            if (log_q_z_x) log_q_z_x[row] = lq;
+            if (log_p_z) log_p_z[row] = lp;
+        }
+    }
+}
+
 static bool vec_ok(int D, int* G) {
     if (D % 4 != 0) return false;
     const int g = D / 4;
@@ -190,6 +228,15 @@ int lvae_launch_sample_iw(bool from_eps, const float* mu, const float* logvar, c
                           float* log_q_z_x, float* log_p_z, float* iw_ll, hipStream_t st) {
     int G = 0;
     const dim3 grid((unsigned)B);
+    if (!from_eps && !iw_ll && vec_ok(D, &G)) {
+        const int64_t rows = B * K;
+        int64_t blocks = lvae_ceil_div(rows, 256 / G);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(sample_ll_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, mu, logvar, src,
+                           rows, K, D, G, log_q_z_x, log_p_z);
+        LVAE_LAUNCH_CHECK();
+        return LVAE_OK;
+    }
     if (vec_ok(D, &G)) {
         if (from_eps)
             hipLaunchKernelGGL(sample_iw_kernel<true>, grid, dim3(256), 0, st, mu, logvar, src, log_p_x_z,
@@ -222,6 +269,94 @@ int lvae_launch_iw_lse(const float* a, const float* b, const float* c, int64_t B
                        hipStream_t st) {
     hipLaunchKernelGGL(iw_lse_kernel, dim3((unsigned)lvae_ceil_div(B, 4)), dim3(256), 0, st, a, b, c, B,
                        K, out);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+// ---- fused per-sample densities + float64 sums ------------------------------------------------------
+// For rows i < M (z_i drawn from posterior i): log p(z_i) and log q(z_i|x_i) are evaluated on the fly
+// and summed in float64 together with the given per-sample log q(z_i) (and prod-marginals) vectors:
+//   sums = [ sum log q(z), sum log prod-marg, sum log p(z), sum log q(z|x), M ]
+// These are the four means that loss_and_optimisation.py:816-824 turns into MI / TC / dim-KL /
+// marginal-KL.  One pass over z, mu, logvar (12*D bytes per row): HBM-bound.
+__global__ void __launch_bounds__(256)
+latent_sums_kernel(const float* __restrict__ z, const float* __restrict__ mu,
+                   const float* __restrict__ logvar, const float* __restrict__ log_qz,
+                   const float* __restrict__ log_qz_pm, int64_t M, int D, int G,
+                   double* __restrict__ sums) {
+    double a_lq = 0.0, a_pm = 0.0, a_lp = 0.0, a_lqx = 0.0;
+    if (G > 0) {
+        const int gl = threadIdx.x % G;
+        const int64_t rows_per_pass = (int64_t)gridDim.x * (256 / G);
+        for (int64_t base = (int64_t)blockIdx.x * (256 / G); base < M; base += rows_per_pass) {
+            const int64_t row = base + threadIdx.x / G;
+            const bool ok = row < M;
+            float lq = 0.f, lp = 0.f;
+            if (ok) {
+                const f32x4 zz = *reinterpret_cast<const f32x4*>(z + row * D + 4 * gl);
+                const f32x4 mm = *reinterpret_cast<const f32x4*>(mu + row * D + 4 * gl);
+                const f32x4 lv = *reinterpret_cast<const f32x4*>(logvar + row * D + 4 * gl);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float df = zz[e] - mm[e];
+                    lq += -0.5f * (lv[e] + LVAE_LOG_2PI + __fdiv_rn(df * df, expf(lv[e])));
+                    lp += -0.5f * (LVAE_LOG_2PI + zz[e] * zz[e]);
+                }
+            }
+            lq = group_sum(lq, G);
+            lp = group_sum(lp, G);
+            if (ok && gl == 0) {
+                a_lqx += (double)lq;
+                a_lp += (double)lp;
+                if (log_qz) a_lq += (double)log_qz[row];
+                if (log_qz_pm) a_pm += (double)log_qz_pm[row];
+            }
+        }
+    } else {
+        for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < M; row += (int64_t)gridDim.x * 256) {
+            float lq = 0.f, lp = 0.f;
+            for (int d = 0; d < D; ++d) {
+                const float zz = z[row * D + d], mm = mu[row * D + d], lv = logvar[row * D + d];
+                const float df = zz - mm;
+                lq += -0.5f * (lv + LVAE_LOG_2PI + __fdiv_rn(df * df, expf(lv)));
+                lp += -0.5f * (LVAE_LOG_2PI + zz * zz);
+            }
+            a_lqx += (double)lq;
+            a_lp += (double)lp;
+            if (log_qz) a_lq += (double)log_qz[row];
+            if (log_qz_pm) a_pm += (double)log_qz_pm[row];
+        }
+    }
+    __shared__ double sm[4][4];
+    a_lq = wave_sum_d(a_lq);
+    a_pm = wave_sum_d(a_pm);
+    a_lp = wave_sum_d(a_lp);
+    a_lqx = wave_sum_d(a_lqx);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sm[0][w] = a_lq;
+        sm[1][w] = a_pm;
+        sm[2][w] = a_lp;
+        sm[3][w] = a_lqx;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const double t = sm[threadIdx.x][0] + sm[threadIdx.x][1] + sm[threadIdx.x][2] + sm[threadIdx.x][3];
+        atomicAdd(&sums[threadIdx.x], t);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) sums[4] = (double)M;
+}
+
+int lvae_launch_latent_sums(const float* z, const float* mu, const float* logvar, const float* log_qz,
+                            const float* log_qz_pm, int64_t M, int D, double* sums, hipStream_t st) {
+    int G = 0;
+    if (!vec_ok(D, &G)) G = 0;
+    const int64_t rows_per_block = G ? 256 / G : 256;
+    int64_t blocks = lvae_ceil_div(M, rows_per_block);
+    if (blocks > 2048) blocks = 2048;
+    LVAE_HIP(hipMemsetAsync(sums, 0, 5 * sizeof(double), st));
+    hipLaunchKernelGGL(latent_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, st, z, mu, logvar, log_qz,
+                       log_qz_pm, M, D, G, sums);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }

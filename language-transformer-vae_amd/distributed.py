@@ -58,13 +58,14 @@ def hip_local_stats(mu_all, logvar_all, z_local, mu_local, logvar_local, log_nor
     from . import _native as N
     from . import estimators as E
     log_q_z, log_q_z_pm = E.log_qz_raw(mu_all, logvar_all, z_local, log_norm, prod_marginals)
-    log_p_z = E.sample_log_likelihood(z_local, reduce_batch_dim=False)
-    log_q_z_x = E.sample_log_likelihood(z_local, mu_local, logvar_local, reduce_batch_dim=False)
-    sums = [N.reduce_f64(log_q_z),
-            N.reduce_f64(log_q_z_pm) if prod_marginals else torch.zeros((), dtype=torch.float64, device=z_local.device),
-            N.reduce_f64(log_p_z), N.reduce_f64(log_q_z_x),
-            torch.tensor(float(z_local.shape[0]), dtype=torch.float64, device=z_local.device)]
-    return torch.stack(sums), log_q_z
+    z, mu, lv = (N.as_f32(t, n) for t, n in ((z_local, "z"), (mu_local, "mu"), (logvar_local, "logvar")))
+    dev = z.device
+    with torch.cuda.device(dev):
+        sums = torch.empty(5, dtype=torch.float64, device=dev)
+        N.check(N.lib().lvae_latent_sums_f32(N.ptr(z), N.ptr(mu), N.ptr(lv), N.ptr(log_q_z),
+                                             N.ptr(log_q_z_pm), z.shape[0], z.shape[1], N.ptr(sums),
+                                             N.stream_ptr(dev)))
+    return sums, log_q_z
 
 
 def sharded_latent_stats(mu_local, logvar_local, z_local, method="all", dataset_size=None,
