@@ -119,6 +119,62 @@ int lvae_reduce_f32(const float* x, int64_t n, int mode, double scale, double* o
                     int64_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * MI bounds, explicit pair matrices, KL, KDE, MMD.
+ * ------------------------------------------------------------------------------------------- */
+
+/* calc_upper_and_lower_bound_representational_mi (mutual_information.py:218-248) for K diagonal
+ * Gaussians N(mu_j, diag(var_j)) and their samples z_j:  out[0] = InfoNCE lower bound
+ * (mi_lower_bound :135-173), out[1] = MBU upper bound (mi_upper_bound :176-215, the diagonal masked out
+ * of the logsumexp, :207).  `var` is the covariance diagonal as the reference passes it (quirk Q3: the
+ * host hands over std).  out: 2 float64 in device memory. */
+int lvae_pair_bounds_workspace_bytes(int64_t K, int D, int64_t* out_bytes);
+int lvae_pair_bounds_f32(const float* z, const float* mu, const float* var, int64_t K, int D, int path,
+                         double* out, void* ws, int64_t ws_bytes, void* stream);
+
+/* log_prob_pairs (mutual_information.py:108-132) / _gaussian_log_likelihood full branch (:41):
+ * out[j, i] = log N(z_i; mu_j, diag(spread_j)),  out [N, M] (rows = distributions). */
+int lvae_log_prob_pairs_f32(const float* z, const float* mu, const float* spread, int spread_kind,
+                            int64_t M, int64_t N, int D, float* out, void* stream);
+
+/* kl_divergence (loss_and_optimisation.py:14-43): kl = 0.5*(mu^2 + e^logvar - logvar - 1), hinge keeps
+ * kl > lambda (:27-30; lambda <= 0: hinge == kl).  Outputs (each may be NULL): element-wise [N,D] and
+ * latent-summed [N]. */
+int lvae_kl_diag_f32(const float* mu, const float* logvar, int64_t N, int D, float lambda,
+                     float* kl_elem, float* hinge_elem, float* kl_row, float* hinge_row, void* stream);
+
+/* Mean over the rows of x [n, c] -> out [c] (the `.mean(dim=0)` of loss_and_optimisation.py:40-41,:108).
+ * Workspace: 8*c bytes. */
+int lvae_colmean_f32(const float* x, int64_t n, int64_t c, float* out, void* ws, int64_t ws_bytes,
+                     void* stream);
+
+/* GaussianKDE.score_samples (utils_latent_analysis_optimisation.py:33-60): X [n,d] fit points, Y [m,d]
+ * queries, bandwidth bw; out[j] = log(bw^-d * sum_i exp(logN((X_i - Y_j)/bw)) / n), float32 and
+ * unstabilised like the reference (quirk Q6: -inf when every term underflows). */
+int lvae_kde_score_f32(const float* X, const float* Y, int64_t n, int64_t m, int d, float bw, float* out,
+                       void* stream);
+
+/* Gaussian-kernel MMD two-sample statistic with a sum of bandwidths:
+ *     k(a, b) = sum_k exp(-alphas[k] * (dist_eps + |a - b|^2))
+ * unbiased != 0: torch_two_sample.statistics_diff.MMDStatistic.__call__ as used at
+ *   loss_and_optimisation.py:617-619 (dist_eps = 1e-5, diagonals excluded, 1/(n(n-1)) weights) --
+ *   third-party source absent from the reference tree: PARITY UNPINNED, restated from its algorithm;
+ * unbiased == 0: maximum_mean_discrepancy (loss_and_optimisation.py:46-60) with alphas = {1/D^2},
+ *   dist_eps = 0: mean(Kxx) + mean(Kyy) - 2 mean(Kxy), diagonals included.
+ * x [n1,D], y [n2,D] device; alphas: HOST array of n_alpha >= 1 non-negative floats (n_alpha <= 32).
+ * out: 4 float64 in device memory = {statistic, sum Kxx, sum Kyy, sum Kxy}. */
+int lvae_mmd_workspace_bytes(int64_t n1, int64_t n2, int D, int64_t* out_bytes);
+int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int64_t n2, int D, const float* alphas,
+                     int n_alpha, float dist_eps, int unbiased, double* out, void* ws, int64_t ws_bytes,
+                     void* stream);
+
+/* The kernel matrix itself (gaussian_kernel, loss_and_optimisation.py:63-76; MMDStatistic ret_matrix):
+ * out[i, j] = k(x_i, y_j), out [n1, n2]; alphas on the HOST as above.  Workspace: LVAE_KMAT_WS_BYTES. */
+#define LVAE_KMAT_WS_BYTES 4096
+int lvae_kernel_matrix_f32(const float* x, const float* y, int64_t n1, int64_t n2, int D,
+                           const float* alphas, int n_alpha, float dist_eps, float* out, void* ws,
+                           int64_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Measurement aid (no counterpart in the reference): HIP events recorded on the caller's stream
  * around the pair kernels of lvae_log_qz_f32 / lvae_log_qz_partial_f32, so a benchmark can time the
  * dominant kernel alone.  lvae_profile_end synchronises on those events.

@@ -42,11 +42,26 @@ _SIGNATURES = {
                                _i64, ctypes.c_void_p]),
     "lvae_latent_sums_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, ctypes.c_void_p,
                                     ctypes.c_void_p]),
+    "lvae_pair_bounds_workspace_bytes": (_int, [_i64, _int, ctypes.POINTER(_i64)]),
+    "lvae_pair_bounds_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _int, _int, ctypes.c_void_p,
+                                    ctypes.c_void_p, _i64, ctypes.c_void_p]),
+    "lvae_log_prob_pairs_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _int, _i64, _i64, _int, _c_f32p,
+                                       ctypes.c_void_p]),
+    "lvae_kl_diag_f32": (_int, [_c_f32p, _c_f32p, _i64, _int, _f32, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
+                                ctypes.c_void_p]),
+    "lvae_colmean_f32": (_int, [_c_f32p, _i64, _i64, _c_f32p, ctypes.c_void_p, _i64, ctypes.c_void_p]),
+    "lvae_kde_score_f32": (_int, [_c_f32p, _c_f32p, _i64, _i64, _int, _f32, _c_f32p, ctypes.c_void_p]),
+    "lvae_mmd_workspace_bytes": (_int, [_i64, _i64, _int, ctypes.POINTER(_i64)]),
+    "lvae_mmd_rbf_f32": (_int, [_c_f32p, _c_f32p, _i64, _i64, _int, ctypes.POINTER(_f32), _int, _f32, _int,
+                                ctypes.c_void_p, ctypes.c_void_p, _i64, ctypes.c_void_p]),
+    "lvae_kernel_matrix_f32": (_int, [_c_f32p, _c_f32p, _i64, _i64, _int, ctypes.POINTER(_f32), _int, _f32,
+                                      _c_f32p, ctypes.c_void_p, _i64, ctypes.c_void_p]),
     "lvae_profile_begin": (_int, [_int]),
     "lvae_profile_end": (_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_int)]),
 }
 
 REDUCE_WS_BYTES = 8192
+KMAT_WS_BYTES = 4096
 
 
 class LvaeError(RuntimeError):
@@ -118,3 +133,22 @@ def reduce_f64(x, mode=0, scale=1.0):
 def mean_f32(x):
     """Mean of a float32 device vector as a 0-dim float32 tensor (accumulated in float64 on device)."""
     return reduce_f64(x, 0, 1.0 / x.numel()).float()
+
+
+def colmean_f32(x):
+    """Mean over dim 0 of a [n, ...] float32 device tensor -> [...]."""
+    x = as_f32(x, "x")
+    n = x.shape[0]
+    flat = x.reshape(n, -1)
+    c = flat.shape[1]
+    dev = x.device
+    with torch.cuda.device(dev):
+        out = torch.empty(c, dtype=torch.float32, device=dev)
+        ws = workspace(8 * c + 256, dev)
+        check(lib().lvae_colmean_f32(ptr(flat), n, c, ptr(out), ptr(ws), 8 * c + 256, stream_ptr(dev)))
+    return out.reshape(x.shape[1:])
+
+
+def host_floats(values):
+    arr = (ctypes.c_float * len(values))(*[float(v) for v in values])
+    return arr, len(values)

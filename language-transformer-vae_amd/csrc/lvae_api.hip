@@ -7,7 +7,7 @@
 
 // ---- launchers implemented in the kernel files --------------------------------------------------
 int lvae_launch_colsum(const float* mu, int64_t n, int D, PairHeader* hdr, hipStream_t st);
-int lvae_launch_prep(bool gauss, bool frag, const float* x, const float* spread, int spread_kind,
+int lvae_launch_prep(int src, bool frag, const float* x, const float* spread, int spread_kind,
                      int64_t n, int64_t npad, int D, int DP, PairHeader* hdr, int64_t ngauss,
                      float* out, float* bias, float* dparams, int DC, hipStream_t st);
 int lvae_launch_prep_dparams(const float* mu, const float* spread, int spread_kind, int64_t n, int D,
@@ -39,6 +39,27 @@ int lvae_launch_iw_lse(const float* a, const float* b, const float* c, int64_t B
 
 int lvae_launch_latent_sums(const float* z, const float* mu, const float* logvar, const float* log_qz,
                             const float* log_qz_pm, int64_t M, int D, double* sums, hipStream_t st);
+
+int lvae_launch_pair_mfma(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
+                          float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
+                          bool excl, int64_t excl_offset, bool ksum, hipStream_t st);
+int lvae_launch_finalize_ksum(const double* partial, int nsplit, int64_t cpad, int64_t C, double* out,
+                              hipStream_t st);
+int lvae_launch_kl(const float* mu, const float* logvar, int64_t n, int D, float lambda, float* kl_elem,
+                   float* hinge_elem, float* kl_row, float* hinge_row, hipStream_t st);
+int lvae_launch_colmean(const float* x, int64_t n, int64_t c, float* out, double* acc, hipStream_t st);
+int lvae_launch_kde(const float* X, const float* Y, int64_t n, int64_t m, int d, float bw, float* out,
+                    hipStream_t st);
+int lvae_launch_pair_matrix(const float* a, const float* spread, int spread_kind, const float* b,
+                            int64_t na, int64_t nb, int D, int mode, const PairHeader* hdr, float* out,
+                            hipStream_t st);
+int lvae_launch_diag_ll(const float* z, const float* mu, const float* spread, int spread_kind, int64_t n,
+                        int D, float* out, hipStream_t st);
+int lvae_launch_bounds_finalize(const float* diag, const float* lse_all, const float* lse_off, int64_t n,
+                                double* out, hipStream_t st);
+int lvae_launch_set_ksum(PairHeader* hdr, const KsumParams& kp, hipStream_t st);
+int lvae_launch_mmd_stat(const double* sums, int64_t n1, int64_t n2, int unbiased, int zero_alphas,
+                         double* out, hipStream_t st);
 
 // ---- error text, per calling thread --------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -186,11 +207,11 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     if (p.DP) {
         rc = lvae_launch_colsum(mu, N, D, hdr, st);
         if (rc) return rc;
-        rc = lvae_launch_prep(true, true, mu, spread, spread_kind, N, p.nblk * 32, D, p.DP, hdr, N,
+        rc = lvae_launch_prep(0, true, mu, spread, spread_kind, N, p.nblk * 32, D, p.DP, hdr, N,
                               rfrag, rbias, need_direct ? dparams : nullptr, p.DC, st);
         if (rc) return rc;
         if (need_mfma) {
-            rc = lvae_launch_prep(false, false, z, nullptr, 0, M, p.cpad, D, p.DP, hdr, N, cop, nullptr,
+            rc = lvae_launch_prep(1, false, z, nullptr, 0, M, p.cpad, D, p.DP, hdr, N, cop, nullptr,
                                   nullptr, p.DC, st);
             if (rc) return rc;
         }
@@ -276,10 +297,10 @@ extern "C" int lvae_qz_estimate_f32(const float* z, const float* mu, const float
     LVAE_HIP(hipMemsetAsync(hdr, 0, sizeof(PairHeader), st));
     rc = lvae_launch_colsum(mu, N, D, hdr, st);
     if (rc) return rc;
-    rc = lvae_launch_prep(false, true, z, nullptr, 0, M, p.nblk * 32, D, p.DP, hdr, N, rfrag, rbias,
+    rc = lvae_launch_prep(1, true, z, nullptr, 0, M, p.nblk * 32, D, p.DP, hdr, N, rfrag, rbias,
                           nullptr, p.DC, st);
     if (rc) return rc;
-    rc = lvae_launch_prep(true, false, mu, spread, spread_kind, N, p.cpad, D, p.DP, hdr, N, cop, colbias,
+    rc = lvae_launch_prep(0, false, mu, spread, spread_kind, N, p.cpad, D, p.DP, hdr, N, cop, colbias,
                           nullptr, p.DC, st);
     if (rc) return rc;
     rc = lvae_launch_pair_lse_mfma(p, rfrag, rbias, cop, partial, hdr, -1.f, 0, false, 0, st);
@@ -351,4 +372,208 @@ extern "C" int lvae_latent_sums_f32(const float* z, const float* mu, const float
     LVAE_CHECK_ARG(z && mu && logvar && sums, "z, mu, logvar and sums must be non-NULL");
     LVAE_CHECK_ARG(M >= 1 && D >= 1, "need M >= 1 and D >= 1");
     return lvae_launch_latent_sums(z, mu, logvar, log_qz, log_qz_prod_marg, M, D, sums, (hipStream_t)stream);
+}
+
+// ---- MI bounds ---------------------------------------------------------------------------------------
+static size_t bounds_tail_bytes(int64_t K) { return lvae_align256((size_t)K * 3 * sizeof(float)); }
+
+extern "C" int lvae_pair_bounds_workspace_bytes(int64_t K, int D, int64_t* out_bytes) {
+    LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
+    LVAE_CHECK_ARG(K >= 2 && D >= 1 && D <= 4096, "need K >= 2 and 1 <= D <= 4096");
+    const PairPlan p = lvae_make_pair_plan(K, K, D, false);
+    *out_bytes = (int64_t)(p.total + bounds_tail_bytes(K));
+    return LVAE_OK;
+}
+
+extern "C" int lvae_pair_bounds_f32(const float* z, const float* mu, const float* var, int64_t K, int D,
+                                    int path, double* out, void* ws, int64_t ws_bytes, void* stream) {
+    LVAE_CHECK_ARG(out, "out is NULL");
+    LVAE_CHECK_ARG(K >= 2, "the MBU bound needs K >= 2 (got %lld)", (long long)K);
+    int rc = check_pair_shapes(z, mu, var, LVAE_SPREAD_VAR, K, K, D);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const PairPlan p = lvae_make_pair_plan(K, K, D, false);
+    rc = check_ws(ws, ws_bytes, p.total + bounds_tail_bytes(K));
+    if (rc) return rc;
+    float* tail = (float*)((char*)ws + p.total);
+    float *diag = tail, *lse_all = tail + K, *lse_off = tail + 2 * K;
+    rc = run_log_qz(z, mu, var, LVAE_SPREAD_VAR, K, K, D, logf((float)K), 0, 0, path, lse_all, nullptr,
+                    nullptr, nullptr, ws, (int64_t)p.total, st);
+    if (rc) return rc;
+    rc = run_log_qz(z, mu, var, LVAE_SPREAD_VAR, K, K, D, logf((float)(K - 1)), 1, 0, path, lse_off, nullptr,
+                    nullptr, nullptr, ws, (int64_t)p.total, st);
+    if (rc) return rc;
+    rc = lvae_launch_diag_ll(z, mu, var, LVAE_SPREAD_VAR, K, D, diag, st);
+    if (rc) return rc;
+    return lvae_launch_bounds_finalize(diag, lse_all, lse_off, K, out, st);
+}
+
+extern "C" int lvae_log_prob_pairs_f32(const float* z, const float* mu, const float* spread,
+                                       int spread_kind, int64_t M, int64_t N, int D, float* out,
+                                       void* stream) {
+    int rc = check_pair_shapes(z, mu, spread, spread_kind, M, N, D);
+    if (rc) return rc;
+    LVAE_CHECK_ARG(out, "out is NULL");
+    return lvae_launch_pair_matrix(mu, spread, spread_kind, z, N, M, D, 0, nullptr, out, (hipStream_t)stream);
+}
+
+// ---- KL, column means, KDE --------------------------------------------------------------------------
+extern "C" int lvae_kl_diag_f32(const float* mu, const float* logvar, int64_t N, int D, float lambda,
+                                float* kl_elem, float* hinge_elem, float* kl_row, float* hinge_row,
+                                void* stream) {
+    LVAE_CHECK_ARG(mu && logvar, "mu and logvar must be non-NULL");
+    LVAE_CHECK_ARG(N >= 1 && D >= 1, "need N >= 1 and D >= 1");
+    LVAE_CHECK_ARG(kl_elem || hinge_elem || kl_row || hinge_row, "no output requested");
+    return lvae_launch_kl(mu, logvar, N, D, lambda, kl_elem, hinge_elem, kl_row, hinge_row,
+                          (hipStream_t)stream);
+}
+
+extern "C" int lvae_colmean_f32(const float* x, int64_t n, int64_t c, float* out, void* ws,
+                                int64_t ws_bytes, void* stream) {
+    LVAE_CHECK_ARG(x && out, "NULL pointer");
+    LVAE_CHECK_ARG(n >= 1 && c >= 1, "need n >= 1 and c >= 1");
+    int rc = check_ws(ws, ws_bytes, (size_t)c * sizeof(double));
+    if (rc) return rc;
+    return lvae_launch_colmean(x, n, c, out, (double*)ws, (hipStream_t)stream);
+}
+
+extern "C" int lvae_kde_score_f32(const float* X, const float* Y, int64_t n, int64_t m, int d, float bw,
+                                  float* out, void* stream) {
+    LVAE_CHECK_ARG(X && Y && out, "NULL pointer");
+    LVAE_CHECK_ARG(n >= 1 && m >= 1 && d >= 1, "need n, m, d >= 1");
+    LVAE_CHECK_ARG(bw > 0.f, "bandwidth must be positive");
+    return lvae_launch_kde(X, Y, n, m, d, bw, out, (hipStream_t)stream);
+}
+
+// ---- MMD -----------------------------------------------------------------------------------------------
+// Splits the bandwidth list into (count of zeros, KsumParams for the positive ones).  If the positive
+// alphas are all integer multiples (<= LVAE_KSUM_MAX) of the smallest one the sum of exponentials is a
+// polynomial in t = exp(-base*v).
+static int build_ksum(const float* alphas, int n_alpha, float eps, KsumParams* kp, int* zeros) {
+    LVAE_CHECK_ARG(alphas, "alphas is NULL");
+    LVAE_CHECK_ARG(n_alpha >= 1 && n_alpha <= LVAE_KSUM_MAX, "need 1 <= n_alpha <= %d", LVAE_KSUM_MAX);
+    memset(kp, 0, sizeof(*kp));
+    kp->eps = eps;
+    *zeros = 0;
+    float base = 0.f;
+    for (int k = 0; k < n_alpha; ++k) {
+        LVAE_CHECK_ARG(alphas[k] >= 0.f && alphas[k] < 1e30f, "alphas must be finite and non-negative");
+        if (alphas[k] == 0.f) ++*zeros;
+        else if (base == 0.f || alphas[k] < base) base = alphas[k];
+    }
+    if (*zeros == n_alpha) {      // nothing but alpha = 0: every pair contributes n_alpha
+        kp->poly = 1; kp->n = 0; kp->nbase = 0.f; kp->c[0] = 0.f;
+        return LVAE_OK;
+    }
+    bool poly = true;
+    int mmax = 0;
+    for (int k = 0; k < n_alpha && poly; ++k) {
+        if (alphas[k] == 0.f) continue;
+        const double ratio = (double)alphas[k] / (double)base;
+        const double rr = floor(ratio + 0.5);
+        if (fabs(ratio - rr) > 1e-4 * ratio || rr > LVAE_KSUM_MAX) poly = false;
+        else if ((int)rr > mmax) mmax = (int)rr;
+    }
+    if (poly) {
+        kp->poly = 1;
+        kp->n = mmax;
+        kp->nbase = -base * LVAE_LOG2E;
+        for (int k = 0; k < n_alpha; ++k)
+            if (alphas[k] != 0.f) kp->c[(int)floor((double)alphas[k] / (double)base + 0.5)] += 1.0f;
+    } else {
+        kp->poly = 0;
+        int n = 0;
+        for (int k = 0; k < n_alpha; ++k)
+            if (alphas[k] != 0.f) kp->c[n++] = -alphas[k] * LVAE_LOG2E;
+        kp->n = n;
+    }
+    return LVAE_OK;
+}
+
+extern "C" int lvae_mmd_workspace_bytes(int64_t n1, int64_t n2, int D, int64_t* out_bytes) {
+    LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
+    LVAE_CHECK_ARG(n1 >= 2 && n2 >= 2 && D >= 1, "need n1, n2 >= 2 and D >= 1");
+    const int64_t nm = n1 > n2 ? n1 : n2;
+    const PairPlan p = lvae_make_pair_plan(nm, nm, D, false);
+    *out_bytes = (int64_t)(p.total + 256);
+    return LVAE_OK;
+}
+
+// Kernel-matrix sum over (kept = a [na], reduced = b [nb]) into *out (float64, device).
+static int ksum_pass(const float* a, int64_t na, const float* b, int64_t nb, int D, bool excl,
+                     void* ws, double* out, hipStream_t st) {
+    const PairPlan p = lvae_make_pair_plan(nb, na, D, false);
+    char* base = (char*)ws;
+    PairHeader* hdr = (PairHeader*)(base + p.off_hdr);
+    float* rfrag = (float*)(base + p.off_rfrag);
+    float* rbias = (float*)(base + p.off_rbias);
+    float* cop = (float*)(base + p.off_cop);
+    float2* partial = (float2*)(base + p.off_partial);
+    int rc = lvae_launch_prep(2, true, b, nullptr, 0, nb, p.nblk * 32, D, p.DP, hdr, 1, rfrag, rbias, nullptr,
+                              p.DC, st);
+    if (rc) return rc;
+    rc = lvae_launch_prep(1, false, a, nullptr, 0, na, p.cpad, D, p.DP, hdr, 1, cop, nullptr, nullptr, p.DC, st);
+    if (rc) return rc;
+    rc = lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, -1.f, 0, excl, 0, true, st);
+    if (rc) return rc;
+    return lvae_launch_finalize_ksum((const double*)partial, p.nsplit, p.cpad, na, out, st);
+}
+
+extern "C" int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int64_t n2, int D,
+                                const float* alphas, int n_alpha, float dist_eps, int unbiased, double* out,
+                                void* ws, int64_t ws_bytes, void* stream) {
+    LVAE_CHECK_ARG(x && y && out, "x, y and out must be non-NULL");
+    LVAE_CHECK_ARG(n1 >= 2 && n2 >= 2, "need n1, n2 >= 2");
+    LVAE_CHECK_ARG(D >= 1 && D <= 128, "the MMD path needs 1 <= D <= 128 (got %d)", D);
+    LVAE_CHECK_ARG(n1 < (1LL << 31) && n2 < (1LL << 31), "n1, n2 must be below 2^31");
+    KsumParams kp;
+    int zeros = 0;
+    int rc = build_ksum(alphas, n_alpha, dist_eps, &kp, &zeros);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nm = n1 > n2 ? n1 : n2;
+    const PairPlan pmax = lvae_make_pair_plan(nm, nm, D, false);
+    rc = check_ws(ws, ws_bytes, pmax.total + 256);
+    if (rc) return rc;
+    PairHeader* hdr = (PairHeader*)ws;
+    double* sums = (double*)((char*)ws + pmax.total);        // 3 float64 behind the pair workspace
+    LVAE_HIP(hipMemsetAsync(hdr, 0, sizeof(PairHeader), st));   // colsum = 0 -> no centering shift
+    rc = lvae_launch_set_ksum(hdr, kp, st);
+    if (rc) return rc;
+    const bool excl = unbiased != 0;
+    if (kp.n == 0 && kp.c[0] == 0.f) {
+        LVAE_HIP(hipMemsetAsync(sums, 0, 3 * sizeof(double), st));
+    } else {
+        rc = ksum_pass(x, n1, x, n1, D, excl, ws, sums + 0, st);
+        if (rc) return rc;
+        rc = ksum_pass(y, n2, y, n2, D, excl, ws, sums + 1, st);
+        if (rc) return rc;
+        rc = ksum_pass(x, n1, y, n2, D, false, ws, sums + 2, st);
+        if (rc) return rc;
+    }
+    return lvae_launch_mmd_stat(sums, n1, n2, unbiased, zeros, out, st);
+}
+
+extern "C" int lvae_kernel_matrix_f32(const float* x, const float* y, int64_t n1, int64_t n2, int D,
+                                      const float* alphas, int n_alpha, float dist_eps, float* out, void* ws,
+                                      int64_t ws_bytes, void* stream) {
+    LVAE_CHECK_ARG(x && y && out, "x, y and out must be non-NULL");
+    LVAE_CHECK_ARG(n1 >= 1 && n2 >= 1 && D >= 1, "need n1, n2, D >= 1");
+    KsumParams kp;
+    int zeros = 0;
+    int rc = build_ksum(alphas, n_alpha, dist_eps, &kp, &zeros);
+    if (rc) return rc;
+    if (kp.poly) kp.c[0] += (float)zeros;     // alpha = 0 terms: +1 per pair, a constant coefficient
+    else {
+        LVAE_CHECK_ARG(kp.n + zeros <= LVAE_KSUM_MAX, "too many bandwidths");
+        for (int k = 0; k < zeros; ++k) kp.c[kp.n++] = 0.f;
+    }
+    rc = check_ws(ws, ws_bytes, LVAE_KMAT_WS_BYTES);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    PairHeader* hdr = (PairHeader*)ws;
+    static_assert(sizeof(PairHeader) <= LVAE_KMAT_WS_BYTES, "header larger than the kernel-matrix workspace");
+    rc = lvae_launch_set_ksum(hdr, kp, st);
+    if (rc) return rc;
+    return lvae_launch_pair_matrix(x, nullptr, 0, y, n1, n2, D, 1, hdr, out, st);
 }

@@ -1,0 +1,250 @@
+// Small kernels of the latent-analysis path that are not worth a matrix-core formulation at the sizes
+// the reference runs them at: analytic KL (K9), Gaussian KDE scores (K8), explicit pair matrices
+// (log_prob_pairs / gaussian_kernel outputs), the diagonal terms and final means of the MI bounds (K3),
+// column means, and the MMD bookkeeping around the kernel-sum launches.
+#include "pair_plan.h"
+
+// ---- analytic KL and its free-bits variant (loss_and_optimisation.py:14-43) ---------------------
+// kl = 0.5*(mu^2 + exp(logvar) - logvar - 1); hinge keeps entries with kl > lambda (:27-30).
+__global__ void __launch_bounds__(256)
+kl_diag_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, int64_t n, int D,
+               float lambda, float* __restrict__ kl_elem, float* __restrict__ hinge_elem,
+               float* __restrict__ kl_row, float* __restrict__ hinge_row) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int lane = threadIdx.x & 63;
+    float sk = 0.f, sh = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float m = mu[row * D + d], lv = logvar[row * D + d];
+        const float kl = 0.5f * (m * m + expf(lv) - lv - 1.0f);
+        const float hk = lambda > 0.f ? (kl > lambda ? kl : 0.f) : kl;
+        if (kl_elem) kl_elem[row * D + d] = kl;
+        if (hinge_elem) hinge_elem[row * D + d] = hk;
+        sk += kl;
+        sh += hk;
+    }
+    sk = wave_sum(sk);
+    sh = wave_sum(sh);
+    if (lane == 0) {
+        if (kl_row) kl_row[row] = sk;
+        if (hinge_row) hinge_row[row] = sh;
+    }
+}
+
+int lvae_launch_kl(const float* mu, const float* logvar, int64_t n, int D, float lambda, float* kl_elem,
+                   float* hinge_elem, float* kl_row, float* hinge_row, hipStream_t st) {
+    hipLaunchKernelGGL(kl_diag_kernel, dim3((unsigned)lvae_ceil_div(n, 4)), dim3(256), 0, st, mu, logvar, n,
+                       D, lambda, kl_elem, hinge_elem, kl_row, hinge_row);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+// ---- column means of a [n, c] matrix ---------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+colmean_stage1(const float* __restrict__ x, int64_t n, int64_t c, int rows_per_block,
+               double* __restrict__ acc) {
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= c) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > n) r1 = n;
+    double s = 0.0;
+    for (int64_t r = r0; r < r1; ++r) s += (double)x[r * c + col];
+    atomicAdd(&acc[col], s);
+}
+__global__ void colmean_stage2(const double* __restrict__ acc, int64_t c, double scale, float* __restrict__ out) {
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col < c) out[col] = (float)(acc[col] * scale);
+}
+
+int lvae_launch_colmean(const float* x, int64_t n, int64_t c, float* out, double* acc, hipStream_t st) {
+    LVAE_HIP(hipMemsetAsync(acc, 0, sizeof(double) * c, st));
+    const int rows_per_block = 512;
+    const dim3 grid((unsigned)lvae_ceil_div(c, 256), (unsigned)lvae_ceil_div(n, rows_per_block));
+    hipLaunchKernelGGL(colmean_stage1, grid, dim3(256), 0, st, x, n, c, rows_per_block, acc);
+    LVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colmean_stage2, dim3((unsigned)lvae_ceil_div(c, 256)), dim3(256), 0, st, acc, c,
+                       1.0 / (double)n, out);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+// ---- Gaussian KDE scores (utils_latent_analysis_optimisation.py:55-58) ---------------------------
+// out[j] = log( bw^-d * sum_i exp(logN((X_i - Y_j)/bw; 0, I)) / n ), float32 and UNstabilised like the
+// reference (quirk Q6: a query far from every point gives log(0) = -inf).
+__global__ void __launch_bounds__(256)
+kde_score_kernel(const float* __restrict__ X, const float* __restrict__ Y, int64_t n, int64_t m, int d,
+                 float bw, float* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t jj = j < m ? j : m - 1;
+    const float inv_bw = 1.0f / bw;
+    const float lognorm = -0.5f * (float)d * LVAE_LOG_2PI;
+    const float scale = powf(bw, -(float)d);
+    float y0 = Y[jj * d];
+    float acc = 0.f;
+    for (int64_t i = 0; i < n; ++i) {
+        float q = 0.f;
+        if (d == 1) {
+            const float u = (X[i] - y0) * inv_bw;
+            q = u * u;
+        } else {
+            for (int dd = 0; dd < d; ++dd) {
+                const float u = (X[i * d + dd] - Y[jj * d + dd]) * inv_bw;
+                q += u * u;
+            }
+        }
+        acc += scale * expf(-0.5f * q + lognorm);
+    }
+    if (j < m) out[j] = logf(acc / (float)n);
+}
+
+int lvae_launch_kde(const float* X, const float* Y, int64_t n, int64_t m, int d, float bw, float* out,
+                    hipStream_t st) {
+    hipLaunchKernelGGL(kde_score_kernel, dim3((unsigned)lvae_ceil_div(m, 256)), dim3(256), 0, st, X, Y, n, m,
+                       d, bw, out);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+// ---- explicit pair matrices ---------------------------------------------------------------------------
+// mode 0: out[j, i] = log N(b_i; a_j, diag(var_j))          (log_prob_pairs, mutual_information.py:108-132;
+//                                                             _gaussian_log_likelihood full branch :41)
+// mode 1: out[j, i] = sum_k exp(-alpha_k * (eps + |a_j - b_i|^2))   (gaussian_kernel / MMD ret_matrix)
+__global__ void __launch_bounds__(256)
+pair_matrix_kernel(const float* __restrict__ a, const float* __restrict__ spread, int spread_kind,
+                   const float* __restrict__ b, int64_t na, int64_t nb, int D, int mode,
+                   const PairHeader* __restrict__ hdr, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
+    const int64_t j = (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (i >= nb || j >= na) return;
+    if (mode == 0) {
+        float acc = 0.f;
+        for (int d = 0; d < D; ++d) {
+            const float sp = spread[j * D + d];
+            const float var = spread_kind == LVAE_SPREAD_VAR ? sp : expf(sp);
+            const float lv = spread_kind == LVAE_SPREAD_VAR ? logf(sp) : sp;
+            const float df = b[i * D + d] - a[j * D + d];
+            acc += lv + LVAE_LOG_2PI + __fdiv_rn(df * df, var);
+        }
+        out[j * nb + i] = -0.5f * acc;
+    } else {
+        float d2 = 0.f;
+        for (int d = 0; d < D; ++d) {
+            const float df = a[j * D + d] - b[i * D + d];
+            d2 += df * df;
+        }
+        const KsumParams* kp = &hdr->ksum;
+        const float v = fabsf(d2) + kp->eps;
+        float f = 0.f;
+        if (kp->poly) {
+            const float t = exp2f(v * kp->nbase);
+            f = kp->c[kp->n];
+            for (int k = kp->n - 1; k >= 0; --k) f = fmaf(f, t, kp->c[k]);
+        } else {
+            for (int k = 0; k < kp->n; ++k) f += exp2f(v * kp->c[k]);
+        }
+        out[j * nb + i] = f;
+    }
+}
+
+int lvae_launch_pair_matrix(const float* a, const float* spread, int spread_kind, const float* b,
+                            int64_t na, int64_t nb, int D, int mode, const PairHeader* hdr, float* out,
+                            hipStream_t st) {
+    const dim3 grid((unsigned)lvae_ceil_div(nb, 16), (unsigned)lvae_ceil_div(na, 16));
+    hipLaunchKernelGGL(pair_matrix_kernel, grid, dim3(256), 0, st, a, spread, spread_kind, b, na, nb, D, mode,
+                       hdr, out);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+// ---- MI bounds: diagonal terms and final means ---------------------------------------------------------
+// diag[i] = log N(z_i; mu_i, diag(var_i)); lower = mean(diag - lse_all), upper = mean(diag - lse_off)
+// (mutual_information.py:165-171, :204-213; the -log K / -log(K-1) are already in the lse vectors).
+__global__ void __launch_bounds__(256)
+diag_ll_kernel(const float* __restrict__ z, const float* __restrict__ mu, const float* __restrict__ spread,
+               int spread_kind, int64_t n, int D, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.f;
+    for (int d = 0; d < D; ++d) {
+        const float sp = spread[i * D + d];
+        const float var = spread_kind == LVAE_SPREAD_VAR ? sp : expf(sp);
+        const float lv = spread_kind == LVAE_SPREAD_VAR ? logf(sp) : sp;
+        const float df = z[i * D + d] - mu[i * D + d];
+        acc += lv + LVAE_LOG_2PI + __fdiv_rn(df * df, var);
+    }
+    out[i] = -0.5f * acc;
+}
+
+__global__ void __launch_bounds__(256)
+bounds_finalize_kernel(const float* __restrict__ diag, const float* __restrict__ lse_all,
+                       const float* __restrict__ lse_off, int64_t n, double* __restrict__ out) {
+    double lo = 0.0, up = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        lo += (double)diag[i] - (double)lse_all[i];
+        up += (double)diag[i] - (double)lse_off[i];
+    }
+    lo = wave_sum_d(lo);
+    up = wave_sum_d(up);
+    __shared__ double sm[2][4];
+    if ((threadIdx.x & 63) == 0) {
+        sm[0][threadIdx.x >> 6] = lo;
+        sm[1][threadIdx.x >> 6] = up;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = (sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3]) / (double)n;
+        out[1] = (sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3]) / (double)n;
+    }
+}
+
+int lvae_launch_diag_ll(const float* z, const float* mu, const float* spread, int spread_kind, int64_t n,
+                        int D, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(diag_ll_kernel, dim3((unsigned)lvae_ceil_div(n, 256)), dim3(256), 0, st, z, mu, spread,
+                       spread_kind, n, D, out);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+int lvae_launch_bounds_finalize(const float* diag, const float* lse_all, const float* lse_off, int64_t n,
+                                double* out, hipStream_t st) {
+    hipLaunchKernelGGL(bounds_finalize_kernel, dim3(1), dim3(256), 0, st, diag, lse_all, lse_off, n, out);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+// ---- MMD bookkeeping -----------------------------------------------------------------------------------
+__global__ void set_ksum_kernel(PairHeader* hdr, const KsumParams kp) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) hdr->ksum = kp;
+}
+
+// sums: [Sxx, Syy, Sxy] of the kernels with alpha > 0; zero_alphas bandwidths with alpha == 0 add
+// exactly 1 per counted pair.  out = [stat, Sxx, Syy, Sxy] (totals).
+__global__ void mmd_stat_kernel(const double* __restrict__ sums, double n1, double n2, int unbiased,
+                                double zero_alphas, double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double c11 = unbiased ? n1 * (n1 - 1.0) : n1 * n1;
+    const double c22 = unbiased ? n2 * (n2 - 1.0) : n2 * n2;
+    const double c12 = n1 * n2;
+    const double sxx = sums[0] + zero_alphas * c11;
+    const double syy = sums[1] + zero_alphas * c22;
+    const double sxy = sums[2] + zero_alphas * c12;
+    out[0] = sxx / c11 + syy / c22 - 2.0 * sxy / c12;
+    out[1] = sxx;
+    out[2] = syy;
+    out[3] = sxy;
+}
+
+int lvae_launch_set_ksum(PairHeader* hdr, const KsumParams& kp, hipStream_t st) {
+    hipLaunchKernelGGL(set_ksum_kernel, dim3(1), dim3(64), 0, st, hdr, kp);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+int lvae_launch_mmd_stat(const double* sums, int64_t n1, int64_t n2, int unbiased, int zero_alphas,
+                         double* out, hipStream_t st) {
+    hipLaunchKernelGGL(mmd_stat_kernel, dim3(1), dim3(64), 0, st, sums, (double)n1, (double)n2, unbiased,
+                       (double)zero_alphas, out);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}

@@ -41,7 +41,13 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 }
 #define LSE_MINIT (-1.0e30f)
 
-template <int DP, int NCB, int WPS, bool EXCL>
+// EPI 0: streaming logsumexp (log q(z), q_z_estimate, MI bounds).
+// EPI 1: kernel-matrix column sums.  The contraction is the squared distance d2 = |x - y|^2 (POINT x
+//        SAMPLE operands) and every pair contributes f(d2) = sum_k exp(-alpha_k * (eps + |d2|)),
+//        accumulated per column in float64 (one tile's 16 terms are first summed in float32).
+//        poly mode: alpha_k = base * (integer), f is a polynomial in t = exp(-base*v) evaluated by
+//        Horner's rule (one v_exp_f32 per pair for any number of bandwidths).
+template <int DP, int NCB, int WPS, bool EXCL, int EPI>
 __global__ void __launch_bounds__(256, WPS)
 pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ rbias,
                      const float* __restrict__ cop, float2* __restrict__ partial,
@@ -76,10 +82,14 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     }
 
     float m[NCB], s[NCB];
+    double ks[NCB];       // EPI 1: float64 column sums
+    float kt[NCB];        // EPI 1: float32 sum of the tile in flight
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         m[cb] = LSE_MINIT;
         s[cb] = 0.f;
+        ks[cb] = 0.0;
+        kt[cb] = 0.f;
     }
 
     const int64_t b0 = (int64_t)blockIdx.y * blk_per_split;
@@ -142,7 +152,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (want == 8 * g + 4 * h + e) acc[cb][4 * g + e] = -INFINITY;
+                        if (want == 8 * g + 4 * h + e) acc[cb][4 * g + e] = EPI == 1 ? INFINITY : -INFINITY;
             }
         }
     };
@@ -151,10 +161,32 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     // each one issues in the shadow of one MFMA of the NEXT block (64 cycles of matrix-pipe time):
     //   0: max of elements 0..7        1: max of 8..15, lazy rescale of the running (max, sum)
     //   2..9: two exponentials each, added to the running sum.
-    constexpr int EPI_MS = 10;
+    // (EPI 1: 17 micro-slices: one pair each, the last one folds the tile sum into float64.)
+    constexpr int EPI_MS = EPI == 1 ? 17 : 10;
     float tmax[NCB];
+    const KsumParams* __restrict__ kp = &hdr->ksum;     // wave-uniform: scalar loads
+    auto kfun = [&](float d2) -> float {
+        const float v = fabsf(d2) + kp->eps;
+        const int n = kp->n;
+        if (kp->poly) {
+            const float t = lvae_exp2(v * kp->nbase);
+            float pacc = kp->c[n];
+            for (int k = n - 1; k >= 0; --k) pacc = fmaf(pacc, t, kp->c[k]);
+            return pacc;
+        }
+        float f = 0.f;
+        for (int k = 0; k < n; ++k) f += lvae_exp2(v * kp->c[k]);
+        return f;
+    };
     auto epi_micro = [&](const f32x16 (&prev)[NCB], int cb, int ms) {
-        if (ms == 0) {
+        if (EPI == 1) {
+            if (ms < 16) {
+                kt[cb] += kfun(prev[cb][ms]);
+            } else {
+                ks[cb] += (double)kt[cb];
+                kt[cb] = 0.f;
+            }
+        } else if (ms == 0) {
             float t = prev[cb][0];
 #pragma unroll
             for (int e = 1; e < 8; ++e) t = fmaxf(t, prev[cb][e]);
@@ -179,8 +211,6 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     };
     constexpr int SLOTS = DP * NCB;                    // MFMAs per block
     constexpr int MS_TOTAL = EPI_MS * NCB;             // micro-slices per block
-    constexpr int MS_STRIDE = SLOTS / MS_TOTAL > 0 ? SLOTS / MS_TOTAL : 1;
-    static_assert(MS_TOTAL <= SLOTS, "epilogue does not fit under one block of MFMAs");
 
     // Values carried from the tail of one chunk into the next: the first 1 KiB piece of the next chunk
     // and (at a block boundary) the next block's row biases, both already read from LDS.
@@ -232,9 +262,10 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
                                                                        st == 0 ? cv : acc[cb], 0, 0, 0);
                         const int u = st * NCB + cb;
 #ifndef LVAE_DBG_NOEPI
-                        if (with_epi && u % MS_STRIDE == (MS_STRIDE > 1 ? 1 : 0) && u / MS_STRIDE < MS_TOTAL) {
-                            const int k = u / MS_STRIDE;
-                            epi_micro(prev, k / EPI_MS, k % EPI_MS);
+                        if (with_epi) {   // micro-slices spread evenly over the block's MFMA slots
+#pragma unroll
+                            for (int k = (u * MS_TOTAL) / SLOTS; k < ((u + 1) * MS_TOTAL) / SLOTS; ++k)
+                                epi_micro(prev, k / EPI_MS, k % EPI_MS);
                         }
 #endif
                         __builtin_amdgcn_sched_barrier(0);
@@ -287,6 +318,15 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     }
 
     // merge the two half-waves (same column, complementary rows) and publish
+    if (EPI == 1) {
+        double* kpartial = reinterpret_cast<double*>(partial);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const double tot = ks[cb] + __shfl_xor(ks[cb], 32, 64);
+            if (h == 0) kpartial[(int64_t)blockIdx.y * cpad + col0 + cb * 32 + r] = tot;
+        }
+        return;
+    }
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         const float mo = __shfl_xor(m[cb], 32, 64);
@@ -300,34 +340,47 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
 template <int DP, int NCB, int WPS>
 static int launch_t(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                     float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
-                    bool excl, int64_t excl_offset, hipStream_t st) {
+                    bool excl, int64_t excl_offset, bool ksum, hipStream_t st) {
     const dim3 grid((unsigned)(p.cpad / (4 * 32 * NCB)), (unsigned)p.nsplit);
-    if (excl)
-        hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, NCB, WPS, true>), grid, dim3(256), 0, st, rfrag,
-                           rbias, cop, partial, hdr, cond_limit, use_if_above, p.nblk,
-                           p.blk_per_split, p.cpad, excl_offset);
-    else
-        hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, NCB, WPS, false>), grid, dim3(256), 0, st, rfrag,
-                           rbias, cop, partial, hdr, cond_limit, use_if_above, p.nblk,
-                           p.blk_per_split, p.cpad, excl_offset);
+#define LVAE_PAIR(X, E)                                                                              \
+    hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, NCB, WPS, X, E>), grid, dim3(256), 0, st, rfrag, rbias, \
+                       cop, partial, hdr, cond_limit, use_if_above, p.nblk, p.blk_per_split, p.cpad,  \
+                       excl_offset)
+    if (ksum) {
+        if (excl) LVAE_PAIR(true, 1);
+        else LVAE_PAIR(false, 1);
+    } else {
+        if (excl) LVAE_PAIR(true, 0);
+        else LVAE_PAIR(false, 0);
+    }
+#undef LVAE_PAIR
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }
 
 // cond_limit < 0: run unconditionally.  Otherwise run iff (cond > cond_limit) == use_if_above.
-int lvae_launch_pair_lse_mfma(const PairPlan& p, const float* rfrag, const float* rbias,
-                              const float* cop, float2* partial, const PairHeader* hdr,
-                              float cond_limit, int use_if_above, bool excl, int64_t excl_offset,
-                              hipStream_t st) {
+// ksum == false: logsumexp epilogue; true: kernel-matrix column sums (float64 partials; parameters in
+// hdr->ksum).
+int lvae_launch_pair_mfma(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
+                          float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
+                          bool excl, int64_t excl_offset, bool ksum, hipStream_t st) {
     if (p.cpad % (4 * 32 * p.NCB) != 0)
         return lvae_set_error(LVAE_ERR_INVALID, "pair plan: cpad %lld not a multiple of the tile",
                               (long long)p.cpad);
     switch (p.DP) {
-        case 16: return launch_t<16, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, st);
-        case 32: return launch_t<32, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, st);
-        case 64: return launch_t<64, 1, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, st);
-        case 128: return launch_t<128, 1, 1>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, st);
+        case 16: return launch_t<16, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, ksum, st);
+        case 32: return launch_t<32, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, ksum, st);
+        case 64: return launch_t<64, 1, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, ksum, st);
+        case 128: return launch_t<128, 1, 1>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, ksum, st);
         default:
             return lvae_set_error(LVAE_ERR_UNSUPPORTED, "MFMA path needs D <= 128 (got D=%d)", p.D);
     }
+}
+
+int lvae_launch_pair_lse_mfma(const PairPlan& p, const float* rfrag, const float* rbias,
+                              const float* cop, float2* partial, const PairHeader* hdr,
+                              float cond_limit, int use_if_above, bool excl, int64_t excl_offset,
+                              hipStream_t st) {
+    return lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl,
+                                 excl_offset, false, st);
 }

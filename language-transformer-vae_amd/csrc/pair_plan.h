@@ -4,11 +4,24 @@
 #include <stdlib.h>
 #include "lvae_common.h"
 
+// Parameters of the kernel-matrix epilogue: f(v) = sum_k exp(-alpha_k v), v = eps + |d2|.
+// poly: c[0..n] are the coefficients of a polynomial in t = exp2(v * nbase); else c[k] = -alpha_k*log2e.
+#define LVAE_KSUM_MAX 32
+struct KsumParams {
+    int poly;
+    int n;
+    float eps;
+    float nbase;
+    float c[LVAE_KSUM_MAX + 1];
+};
+
 // Lives at the start of the workspace; zeroed (hipMemsetAsync) at the start of every call.
 struct PairHeader {
     double colsum[128];      // per-dimension sum of the posterior means (centering shift * R_gauss)
     unsigned int cond_bits;  // float bits of max_j conditioning estimate (non-negative -> uint order)
     unsigned int pad_[63];
+    KsumParams ksum;         // kernel-matrix epilogue parameters (copied in by the MMD entry point)
+    unsigned int pad2_[27];
 };
 
 struct PairPlan {

@@ -53,15 +53,19 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ m
 }
 
 // One thread per (row, 4 consecutive dimensions); a block covers 32 rows (= one fragment block).
-// GAUSS rows come from (mu, spread), SAMPLE rows from z.  FRAG selects the fragment-major
+// SRC 0 (GAUSS): rows from (mu, spread); SRC 1 (SAMPLE): rows from z -> (z^2, z);
+// SRC 2 (POINT): rows from y -> (1, -2y) with bias |y|^2, so that the contraction with a SAMPLE operand
+// is the squared distance |x - y|^2 (kernel-matrix sums; padded rows get +inf).  FRAG selects the fragment-major
 // reduced-axis layout (threads ordered row-fastest so that each wave stores whole 512-B runs),
 // otherwise row-major [row][2*DP] for the kept axis (threads ordered dimension-fastest).
-template <bool GAUSS, bool FRAG>
+template <int SRC, bool FRAG>
 __global__ void __launch_bounds__(1024)
 prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ spread, int spread_kind,
                     int64_t n, int64_t npad, int D, int DP, PairHeader* hdr, double inv_ngauss,
                     float* __restrict__ out, float* __restrict__ bias, float* __restrict__ dparams,
                     int DC) {
+    constexpr bool GAUSS = SRC == 0;
+    constexpr bool POINT = SRC == 2;
     __shared__ float sm_shift[128];
     __shared__ float sm_c[1024];
     __shared__ float sm_k[1024];
@@ -97,6 +101,10 @@ prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ sprea
                         dparams[(row * 3 + 1) * DC + d] = sqrtf(0.5f * LVAE_LOG2E * p);
                         dparams[(row * 3 + 2) * DC + d] = -0.5f * LVAE_LOG2E * (logvar + LVAE_LOG_2PI);
                     }
+                } else if (POINT) {
+                    v0[e] = 1.0f;
+                    v1[e] = -2.0f * xs;
+                    csum += xs * xs;
                 } else {
                     v0[e] = xs * xs;
                     v1[e] = xs;
@@ -129,8 +137,8 @@ prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ sprea
                 k += sm_k[r * NQ + j];
             }
             if (bias) {
-                float b = GAUSS ? -0.5f * LVAE_LOG2E * c : 0.f;
-                if (!valid) b = FRAG ? -INFINITY : 0.f;
+                float b = GAUSS ? -0.5f * LVAE_LOG2E * c : (POINT ? c : 0.f);
+                if (!valid) b = FRAG ? (POINT ? INFINITY : -INFINITY) : 0.f;
                 bias[row] = b;
             }
             if (GAUSS && valid) atomicMax(&hdr->cond_bits, __float_as_uint(k));
@@ -218,19 +226,21 @@ int lvae_launch_colsum(const float* mu, int64_t n, int D, PairHeader* hdr, hipSt
     return LVAE_OK;
 }
 
-int lvae_launch_prep(bool gauss, bool frag, const float* x, const float* spread, int spread_kind,
+int lvae_launch_prep(int src, bool frag, const float* x, const float* spread, int spread_kind,
                      int64_t n, int64_t npad, int D, int DP, PairHeader* hdr, int64_t ngauss,
                      float* out, float* bias, float* dparams, int DC, hipStream_t st) {
     const int threads = 32 * (DP / 4);
     const dim3 grid((unsigned)lvae_ceil_div(npad, 32));
     const double inv = 1.0 / (double)ngauss;
-#define LVAE_PREP(G, F)                                                                          \
-    hipLaunchKernelGGL((prep_operand_kernel<G, F>), grid, dim3(threads), 0, st, x, spread,        \
+#define LVAE_PREP(S, F)                                                                          \
+    hipLaunchKernelGGL((prep_operand_kernel<S, F>), grid, dim3(threads), 0, st, x, spread,        \
                        spread_kind, n, npad, D, DP, hdr, inv, out, bias, dparams, DC)
-    if (gauss && frag) LVAE_PREP(true, true);
-    else if (gauss) LVAE_PREP(true, false);
-    else if (frag) LVAE_PREP(false, true);
-    else LVAE_PREP(false, false);
+    if (src == 0 && frag) LVAE_PREP(0, true);
+    else if (src == 0) LVAE_PREP(0, false);
+    else if (src == 1 && frag) LVAE_PREP(1, true);
+    else if (src == 1) LVAE_PREP(1, false);
+    else if (src == 2 && frag) LVAE_PREP(2, true);
+    else return lvae_set_error(LVAE_ERR_INVALID, "prep: unsupported operand source");
 #undef LVAE_PREP
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
@@ -260,6 +270,31 @@ int lvae_launch_finalize_pm(const float2* partial, int nsplit, int64_t cpad, int
                             float log_norm, float* out, hipStream_t st) {
     hipLaunchKernelGGL(finalize_pm_kernel, dim3((unsigned)lvae_ceil_div(C, 256)), dim3(256), 0, st,
                        partial, nsplit, cpad, C, D, DC, log_norm, out);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+// Sum of the per-column kernel sums (float64 partials [nsplit][cpad]) over the valid columns.
+__global__ void __launch_bounds__(256) finalize_ksum_kernel(const double* __restrict__ partial, int nsplit,
+                                                            int64_t cpad, int64_t C, double* __restrict__ out) {
+    double acc = 0.0;
+    for (int k = 0; k < nsplit; ++k)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < C; i += (int64_t)gridDim.x * 256)
+            acc += partial[k * cpad + i];
+    acc = wave_sum_d(acc);
+    __shared__ double sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
+}
+
+int lvae_launch_finalize_ksum(const double* partial, int nsplit, int64_t cpad, int64_t C, double* out,
+                              hipStream_t st) {
+    int64_t blocks = lvae_ceil_div(C, 256);
+    if (blocks > 256) blocks = 256;
+    LVAE_HIP(hipMemsetAsync(out, 0, sizeof(double), st));
+    hipLaunchKernelGGL(finalize_ksum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, partial, nsplit, cpad,
+                       C, out);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }

@@ -95,13 +95,132 @@ def sample_log_likelihood(latent_z, mu=None, logvar=None, reduce_latent_dim=True
             N.check(N.lib().lvae_sample_ll_elem_f32(N.ptr(z), N.ptr(mu2), N.ptr(lv2), B, K, D, N.ptr(out),
                                                     N.stream_ptr(dev)))
     if reduce_batch_dim:                                  # :107-108 mean over dim 0
-        if out.dim() <= 1:
-            return N.mean_f32(out)
-        flat = out.reshape(out.shape[0], -1)
-        cols = torch.stack([N.mean_f32(flat[:, c]) for c in range(flat.shape[1])]) \
-            if flat.shape[1] <= 64 else flat.mean(dim=0)
-        return cols.reshape(out.shape[1:])
+        return N.mean_f32(out) if out.dim() <= 1 else N.colmean_f32(out)
     return out
+
+
+def kl_divergence(mu, logvar, hinge_kl_loss_lambda=0.5, average_batch=True, sum_latent=True):
+    """loss_and_optimisation.py:14-43.  Returns (kl_loss, hinge_kl_loss) with the reference's shapes:
+    0-dim (sum_latent, average_batch), [N] (sum_latent only), [D] (average_batch only) or [N,D]."""
+    mu, logvar = N.as_f32(mu, "mu"), N.as_f32(logvar, "logvar")
+    if mu.dim() != 2 or mu.shape != logvar.shape:
+        raise ValueError("mu and logvar must be [batch, latent] of one shape")
+    n, D = mu.shape
+    dev = mu.device
+    with torch.cuda.device(dev):
+        if sum_latent:
+            kl = torch.empty(n, dtype=torch.float32, device=dev)
+            hk = torch.empty(n, dtype=torch.float32, device=dev)
+            N.check(N.lib().lvae_kl_diag_f32(N.ptr(mu), N.ptr(logvar), n, D, float(hinge_kl_loss_lambda),
+                                             None, None, N.ptr(kl), N.ptr(hk), N.stream_ptr(dev)))
+        else:
+            kl, hk = torch.empty_like(mu), torch.empty_like(mu)
+            N.check(N.lib().lvae_kl_diag_f32(N.ptr(mu), N.ptr(logvar), n, D, float(hinge_kl_loss_lambda),
+                                             N.ptr(kl), N.ptr(hk), None, None, N.stream_ptr(dev)))
+    if average_batch:
+        if sum_latent:
+            return N.mean_f32(kl), N.mean_f32(hk)
+        return N.colmean_f32(kl), N.colmean_f32(hk)
+    return kl, hk
+
+
+def _kernel_matrix(x, y, alphas, dist_eps):
+    x, y = N.as_f32(x, "x"), N.as_f32(y, "y")
+    if x.dim() != 2 or y.dim() != 2 or x.shape[1] != y.shape[1]:
+        raise ValueError("x and y must be [n, D] and [m, D]")
+    dev = x.device
+    arr, na = N.host_floats(alphas)
+    with torch.cuda.device(dev):
+        out = torch.empty(x.shape[0], y.shape[0], dtype=torch.float32, device=dev)
+        ws = N.workspace(N.KMAT_WS_BYTES, dev)
+        N.check(N.lib().lvae_kernel_matrix_f32(N.ptr(x), N.ptr(y), x.shape[0], y.shape[0], x.shape[1], arr, na,
+                                               float(dist_eps), N.ptr(out), N.ptr(ws), N.KMAT_WS_BYTES,
+                                               N.stream_ptr(dev)))
+    return out
+
+
+def gaussian_kernel(x, y):
+    """loss_and_optimisation.py:63-76: exp(-mean_d((x_i - y_j)^2) / D) = exp(-|x_i - y_j|^2 / D^2), the
+    full [n, m] matrix.  Like the reference's ``torch.tensor(...)`` wrap (:76, quirk Q5) the result carries
+    no gradient."""
+    dim = x.shape[1]
+    return _kernel_matrix(x, y, [1.0 / float(dim * dim)], 0.0)
+
+
+def mmd_rbf(x, y, alphas, dist_eps, unbiased):
+    """Gaussian-kernel MMD between samples x [n1,D] and y [n2,D] without materialising the kernel
+    matrices (fused MFMA distance + kernel-sum pass).  Returns a float64 device tensor
+    [statistic, sum Kxx, sum Kyy, sum Kxy]."""
+    x, y = N.as_f32(x, "x"), N.as_f32(y, "y")
+    if x.dim() != 2 or y.dim() != 2 or x.shape[1] != y.shape[1]:
+        raise ValueError("x and y must be [n1, D] and [n2, D]")
+    n1, n2, D = x.shape[0], y.shape[0], x.shape[1]
+    dev = x.device
+    arr, na = N.host_floats(alphas)
+    with torch.cuda.device(dev):
+        nbytes = N._i64(0)
+        N.check(N.lib().lvae_mmd_workspace_bytes(n1, n2, D, nbytes))
+        ws = N.workspace(nbytes.value, dev)
+        out = torch.empty(4, dtype=torch.float64, device=dev)
+        N.check(N.lib().lvae_mmd_rbf_f32(N.ptr(x), N.ptr(y), n1, n2, D, arr, na, float(dist_eps),
+                                         int(bool(unbiased)), N.ptr(out), N.ptr(ws), nbytes.value,
+                                         N.stream_ptr(dev)))
+    return out
+
+
+def maximum_mean_discrepancy(latent_z, prior_sample=None):
+    """loss_and_optimisation.py:46-60: biased RBF MMD between a standard-normal draw x and latent_z:
+    mean(Kxx) + mean(Kyy) - 2 mean(Kxy).  The reference draws ``x = randn_like(latent_z)`` inside (:53);
+    pass ``prior_sample`` to inject it (parity tests), otherwise it is drawn here the same way."""
+    x = torch.randn_like(latent_z) if prior_sample is None else prior_sample
+    D = latent_z.shape[1]
+    return mmd_rbf(x, latent_z, [1.0 / float(D * D)], 0.0, unbiased=False)[0].float()
+
+
+def get_tts_mmmd(latent_z, prior_sample=None):
+    """LossTermManager.get_tts_mmmd (loss_and_optimisation.py:595-623): torch-two-sample's unbiased MMD
+    between latent_z (squeezed, :596) and a standard-normal draw of the same shape (:597), bandwidths
+    alphas = [0.1*i for i in range(15)] (:598).  PARITY UNPINNED (third-party source absent)."""
+    from .two_sample import MMDStatistic
+    latent_z = latent_z.squeeze(1)
+    if prior_sample is None:
+        prior_sample = torch.randn(latent_z.shape).to(latent_z.device)
+    alphas = [0.1 * i for i in range(15)]
+    n_1, n_2 = len(latent_z), len(prior_sample)
+    return MMDStatistic(n_1, n_2)(latent_z, prior_sample, alphas, ret_matrix=False)
+
+
+def approximate_marginal_KL(mu, logvar, latent_z, method="chen", dataset_size=None, strict=False):
+    """loss_and_optimisation.py:113-121.  As written the reference always raises here (quirk Q1: it asks
+    approximate_log_q_z for ``prod_marginals=False`` with the default ``reduce_mean=True``, :114-115,:219).
+    ``strict=True`` reproduces that; the default returns the value the code is after:
+    mean_i(log q(z_i) - log p(z_i))."""
+    if strict:
+        approximate_log_q_z(mu, logvar, latent_z, method=method, dataset_size=dataset_size,
+                            prod_marginals=False)
+    log_q_z, _ = approximate_log_q_z(mu, logvar, latent_z, method=method, dataset_size=dataset_size,
+                                     prod_marginals=False, reduce_mean=False)
+    log_p_z = sample_log_likelihood(latent_z, reduce_latent_dim=True, reduce_batch_dim=False)
+    return N.mean_f32(log_q_z) - N.mean_f32(log_p_z)
+
+
+def approximate_total_correlation(mu, logvar, latent_z, method="chen", dataset_size=None):
+    """loss_and_optimisation.py:124-136: E[log q(z)] - E[log prod_d q(z_d)]."""
+    log_q_z, log_q_z_prod_marginals = approximate_log_q_z(mu, logvar, latent_z, method=method,
+                                                          dataset_size=dataset_size, prod_marginals=True)
+    return log_q_z - log_q_z_prod_marginals
+
+
+def get_1d_kde_dim_marg_kl_estimate(latents, log_p_z, bw="scott", device=None):
+    """LossTermManager.get_1d_kde_dim_marg_kl_estimate (loss_and_optimisation.py:625-637): every latent
+    coordinate scored under a 1-D Gaussian KDE fitted on all B*D coordinates."""
+    from .kde import GaussianKDE
+    latents_1D = latents.reshape(-1, 1)
+    kde = GaussianKDE(X=latents_1D, bw=bw, device=device)
+    log_q_z_kde = kde.score_samples(Y=latents_1D)                      # [B*D]
+    # .reshape(latents.shape).sum(dim=1).mean(dim=0) (:630-631) == sum of all scores / B
+    log_q_z_kde = N.reduce_f64(log_q_z_kde, 0, 1.0 / latents.shape[0]).float()
+    return log_q_z_kde - log_p_z
 
 
 def iw_log_p_x(log_p_x_z, log_p_z, log_q_z_x):

@@ -1,0 +1,146 @@
+"""Mirror of the estimator functions of NewsVAE/mutual_information.py over the HIP kernels."""
+import math
+
+import torch
+
+from . import _native as N
+
+
+def _spread_pairs(z, mu, spread, spread_kind):
+    z, mu, spread = N.as_f32(z, "sample"), N.as_f32(mu, "mu"), N.as_f32(spread, "var")
+    M, D = z.shape
+    Nn = mu.shape[0]
+    dev = z.device
+    with torch.cuda.device(dev):
+        out = torch.empty(Nn, M, dtype=torch.float32, device=dev)
+        N.check(N.lib().lvae_log_prob_pairs_f32(N.ptr(z), N.ptr(mu), N.ptr(spread), spread_kind, M, Nn, D,
+                                                N.ptr(out), N.stream_ptr(dev)))
+    return out
+
+
+def _gaussian_log_likelihood(sample, mask=None, dim=2, mu=None, var=None):
+    """mutual_information.py:26-41 for the layout q_z_estimate uses: sample [S,1,D] (or [S,D]) against
+    [N,D] parameters, mask == [[1.]], dim == 2 -> [S,N] ([S,1] when no parameters are given).  Missing mu
+    / var mean standard ones (:32-39)."""
+    s = sample.reshape(sample.shape[0], sample.shape[-1])
+    if mask is not None and not bool((mask == 1).all()):
+        raise NotImplementedError("only the all-ones mask the reference uses is supported")
+    if dim != 2:
+        raise NotImplementedError("only dim=2 (the latent axis of [S,1,D]) is supported")
+    S, D = s.shape
+    if mu is None and var is None:
+        mu_, var_ = torch.zeros(1, D, device=s.device), torch.ones(1, D, device=s.device)
+    elif mu is None:
+        mu_, var_ = torch.zeros_like(var), var
+    elif var is None:
+        mu_, var_ = mu, torch.ones_like(mu)
+    else:
+        mu_, var_ = mu, var
+    return _spread_pairs(s, mu_, var_, N.SPREAD_VAR).t().contiguous()
+
+
+def q_z_estimate(z, mu, var, device=None):
+    """mutual_information.py:44-52 including quirk Q2: the logsumexp runs over dim=1 of [1,S,N], the
+    SAMPLE axis, so the result is [1,N]: LSE_i log q(z_i|x_j) - log N for every posterior j.
+    (The reference's debug prints, :49-50, are not reproduced.)"""
+    z, mu, var = N.as_f32(z, "z"), N.as_f32(mu, "mu"), N.as_f32(var, "var")
+    M, D = z.shape
+    Nn = mu.shape[0]
+    dev = z.device
+    with torch.cuda.device(dev):
+        nbytes = N._i64(0)
+        N.check(N.lib().lvae_log_qz_workspace_bytes(Nn, M, D, 0, nbytes))    # roles swapped
+        ws = N.workspace(nbytes.value, dev)
+        out = torch.empty(Nn, dtype=torch.float32, device=dev)
+        N.check(N.lib().lvae_qz_estimate_f32(N.ptr(z), N.ptr(mu), N.ptr(var), N.SPREAD_VAR, M, Nn, D,
+                                             math.log(Nn), N.ptr(out), N.ptr(ws), nbytes.value,
+                                             N.stream_ptr(dev)))
+    return out.unsqueeze(0)
+
+
+def calc_mi_estimate(log_q_z_x, latents, mu, logvar, log_p_z, avg_KL, log_q_z_method="aggregate_posterior",
+                     mi_method="zhao"):
+    """mutual_information.py:56-105, aggregate_posterior branch: log_q_z = LSE(log_q_z_x) - log N over the
+    [N] vector (:85), marg_KL = log_q_z - mean(log_p_z) (:94), MI by Zhao (:98) or Hoffman (:101).
+    Returns (mi_estimate, marg_KL) as Python floats.  The reference's dead "kernel" branch (:73-83) is
+    not provided."""
+    if log_q_z_method != "aggregate_posterior":
+        raise NotImplementedError
+    lq = N.as_f32(log_q_z_x, "log_q_z_x")
+    if lq.dim() != 1:
+        raise ValueError("log_q_z_x must be the [N] vector of log q(z_i|x_i) (a matrix fails at .item() "
+                         "in the reference too)")
+    n = lq.shape[0]
+    dev = lq.device
+    with torch.cuda.device(dev):          # LSE_k(x_k) - log n is the IW reduction of one [1, n] row
+        zeros = torch.zeros(1, n, dtype=torch.float32, device=dev)
+        lse = torch.empty(1, dtype=torch.float32, device=dev)
+        N.check(N.lib().lvae_iw_lse_f32(N.ptr(lq), N.ptr(zeros), N.ptr(zeros), 1, n, N.ptr(lse),
+                                        N.stream_ptr(dev)))
+    log_q_z = lse[0].double()
+    marg_KL = log_q_z - N.reduce_f64(log_p_z, 0, 1.0 / log_p_z.numel())
+    if mi_method == 'zhao':
+        mi_estimate = (N.reduce_f64(lq, 0, 1.0 / n) - log_q_z).item()
+    elif mi_method == 'hoffman':
+        mi_estimate = (float(avg_KL) - marg_KL).item()
+    else:
+        raise ValueError('MI method {} is unknown. Please choose [zhao, hoffman]'.format(mi_method))
+    return mi_estimate, marg_KL.item()
+
+
+def _dists_to_params(dists):
+    """Accept (mu, cov_diag) tensors, or the reference's list of torch distributions
+    (MultivariateNormal with diagonal covariance / Normal)."""
+    if isinstance(dists, (tuple, list)) and len(dists) == 2 and isinstance(dists[0], torch.Tensor):
+        return dists
+    mus, covs = [], []
+    for d in dists:
+        mus.append(d.loc)
+        if hasattr(d, "covariance_matrix"):
+            covs.append(torch.diagonal(d.covariance_matrix))
+        else:
+            covs.append(d.scale ** 2)
+    return torch.stack(mus), torch.stack(covs)
+
+
+def log_prob_pairs(dists, sample_batch):
+    """mutual_information.py:108-132: [K, K] matrix P[j, i] = log p_j(sample_i); rows = distributions."""
+    mu, cov = _dists_to_params(dists)
+    return _spread_pairs(sample_batch.squeeze(), mu, cov, N.SPREAD_VAR)
+
+
+def _bounds(samples, dists):
+    mu, cov = _dists_to_params(dists)
+    z, mu, cov = N.as_f32(samples.squeeze(), "samples"), N.as_f32(mu, "mu"), N.as_f32(cov, "cov")
+    K, D = z.shape
+    dev = z.device
+    with torch.cuda.device(dev):
+        nbytes = N._i64(0)
+        N.check(N.lib().lvae_pair_bounds_workspace_bytes(K, D, nbytes))
+        ws = N.workspace(nbytes.value, dev)
+        out = torch.empty(2, dtype=torch.float64, device=dev)
+        N.check(N.lib().lvae_pair_bounds_f32(N.ptr(z), N.ptr(mu), N.ptr(cov), K, D, N.PATH_AUTO, N.ptr(out),
+                                             N.ptr(ws), nbytes.value, N.stream_ptr(dev)))
+    return out
+
+
+def mi_lower_bound(samples, dists):
+    """mutual_information.py:135-173: InfoNCE lower bound, mean_i(P[i,i] - (LSE_j P[j,i] - log K))."""
+    return _bounds(samples, dists)[0].item()
+
+
+def mi_upper_bound(samples, dists):
+    """mutual_information.py:176-215: MBU upper bound, the diagonal masked out of the logsumexp (:207).
+    Unlike the reference (which builds the mask on the CPU) this runs where the samples are."""
+    return _bounds(samples, dists)[1].item()
+
+
+def calc_upper_and_lower_bound_representational_mi(batch_latent_samples, batch_mu_logvars, gauss_dists=None):
+    """mutual_information.py:218-248.  Quirk Q3 is kept: the distributions are MultivariateNormal(mu,
+    diag(std)) (:240-243), i.e. the covariance diagonal is std = exp(0.5 * logvar)."""
+    if not gauss_dists:
+        mu, logvar = torch.chunk(batch_mu_logvars, 2, dim=1)
+        std = torch.exp(0.5 * logvar)
+        gauss_dists = (mu.contiguous(), std.contiguous())
+    lower, upper = _bounds(batch_latent_samples, gauss_dists).tolist()
+    return lower, upper

@@ -1,0 +1,33 @@
+"""Mirror of the one torch-two-sample entry the reference uses:
+``torch_two_sample.statistics_diff.MMDStatistic`` (call site NewsVAE/loss_and_optimisation.py:617-619).
+
+PARITY UNPINNED: josipd/torch-two-sample is an un-vendored submodule with no pinned revision
+(.gitmodules:4-6); this follows its published algorithm -- pooled Euclidean distances
+sqrt(1e-5 + |a.a + b.b - 2 a.b|), kernel sum_alpha exp(-alpha d^2), unbiased statistic with the
+diagonals removed.  ``pval`` (never called by the reference) is not provided.
+"""
+import torch
+
+from . import _native as N
+from . import estimators as E
+
+PDIST_EPS = 1e-5
+
+
+class MMDStatistic:
+    def __init__(self, n_1, n_2):
+        self.n_1 = n_1
+        self.n_2 = n_2
+        self.a00 = 1. / (n_1 * (n_1 - 1))
+        self.a11 = 1. / (n_2 * (n_2 - 1))
+        self.a01 = - 1. / (n_1 * n_2)
+
+    def __call__(self, sample_1, sample_2, alphas, ret_matrix=False):
+        if sample_1.shape[0] != self.n_1 or sample_2.shape[0] != self.n_2:
+            raise ValueError("sample sizes differ from the ones the statistic was built for")
+        out = E.mmd_rbf(sample_1, sample_2, list(alphas), PDIST_EPS, unbiased=True)
+        mmd = out[0].float()
+        if ret_matrix:
+            s12 = torch.cat((N.as_f32(sample_1, "sample_1"), N.as_f32(sample_2, "sample_2")), 0)
+            return mmd, E._kernel_matrix(s12, s12, list(alphas), PDIST_EPS)
+        return mmd

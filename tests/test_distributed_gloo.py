@@ -1,0 +1,103 @@
+"""world_size-2 CPU (gloo) tests of the multi-GPU layer: row sharding, the padded all-gather of ragged
+shards, the all-reduce of float64 partial sums, the partial-logsumexp combine and the sharded IW gather.
+The per-rank compute is injected (NumPy oracle) because the HIP kernels need a GPU; what is under test
+here is the partition / collective / combine logic, which is backend independent."""
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_local_stats(mu_all, logvar_all, z_local, mu_local, logvar_local, log_norm, prod_marginals):
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import oracle_np as onp
+    mu_a, lv_a, z = (t.numpy().astype(np.float64) for t in (mu_all, logvar_all, z_local))
+    inv = np.exp(-lv_a)
+    dens = -0.5 * (lv_a[None] + onp.LOG_2PI + (z[:, None, :] - mu_a[None]) ** 2 * inv[None])
+    lq = onp._logsumexp(dens.sum(2), 1) - log_norm
+    pm = (onp._logsumexp(dens, 1) - log_norm).sum(1) if prod_marginals else np.zeros(len(z))
+    lp = onp.sample_log_likelihood(z, reduce_batch_dim=False)
+    lqx = onp.sample_log_likelihood(z, mu_local.numpy(), logvar_local.numpy(), reduce_batch_dim=False)
+    sums = torch.tensor([lq.sum(), pm.sum(), lp.sum(), lqx.sum(), float(len(z))], dtype=torch.float64)
+    return sums, torch.from_numpy(lq)
+
+
+def _worker(rank, world, port, n, D, ragged, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lvae import distributed as LD
+    rng = np.random.default_rng(0)
+    mu = rng.standard_normal((n, D)).astype(np.float32)
+    lv = (0.5 * rng.standard_normal((n, D)) - 1).astype(np.float32)
+    z = (mu + rng.standard_normal((n, D)).astype(np.float32) * np.exp(0.5 * lv)).astype(np.float32)
+    if ragged:
+        lo, hi = (0, n // 3) if rank == 0 else (n // 3, n)
+    else:
+        lo, hi = LD.shard_bounds(n, world, rank)
+    t = lambda a: torch.from_numpy(a[lo:hi].copy())
+    out = LD.sharded_latent_stats(t(mu), t(lv), t(z), method="chen", dataset_size=1000, prod_marginals=True,
+                                  local_stats=_oracle_local_stats)
+    # partial-logsumexp combine: every rank holds all z rows but only its posterior columns
+    from oracle import oracle_np as onp
+    dens = onp.log_prob_pairs(z, mu[lo:hi], np.exp(lv[lo:hi].astype(np.float64)))     # [cols, rows]
+    rmax = dens.max(0)
+    rsum = np.exp(dens - rmax[None]).sum(0)
+    comb = LD.combine_partial_lse(torch.from_numpy(rmax).float(), torch.from_numpy(rsum).float(), math.log(n))
+    # ragged all-gather
+    gathered, offs = LD.all_gather_rows(torch.from_numpy(mu[lo:hi].copy()))
+    ok_gather = bool(torch.equal(gathered, torch.from_numpy(mu))) and offs[-1] == n
+    res = {k: v for k, v in out.items() if not isinstance(v, torch.Tensor)}
+    q.put((rank, res, comb.numpy(), ok_gather, out["log_q_z_local"].numpy(), (lo, hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_sharded_latent_stats_world2(ragged):
+    from oracle import oracle_np as onp
+    n, D, world = 96, 16, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, D, ragged, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(0)
+    mu = rng.standard_normal((n, D)).astype(np.float32)
+    lv = (0.5 * rng.standard_normal((n, D)) - 1).astype(np.float32)
+    z = (mu + rng.standard_normal((n, D)).astype(np.float32) * np.exp(0.5 * lv)).astype(np.float32)
+    lq, pm = onp.approximate_log_q_z(mu, lv, z, "chen", 1000, True, False)
+    lp = onp.sample_log_likelihood(z, reduce_batch_dim=False)
+    lqx = onp.sample_log_likelihood(z, mu, lv, reduce_batch_dim=False)
+    want = {"marginal_kl": (lq - lp).mean(), "mi": (lqx - lq).mean(), "tc": (lq - pm).mean(),
+            "dim_kl": (pm - lp).mean(), "n_total": n, "m_total": n}
+    lq_all = onp.approximate_log_q_z(mu, lv, z, "all", None, False, False)[0]
+    for rank, res, comb, ok_gather, lq_local, (lo, hi) in results:
+        assert ok_gather
+        for k, v in want.items():
+            assert abs(res[k] - v) <= 1e-9 * max(1.0, abs(v)), (k, res[k], v)
+        np.testing.assert_allclose(comb, lq_all, rtol=1e-5, atol=1e-4)     # float32 partials
+        np.testing.assert_allclose(lq_local, lq[lo:hi], rtol=1e-12, atol=1e-9)
+    assert results[0][1] == results[1][1]      # identical on every rank

@@ -1,0 +1,185 @@
+"""GPU parity of the remaining hot-path rows against the reference's golden
+vectors: analytic KL, MI bounds (Q3), q_z_estimate (Q2), _gaussian_log_likelihood, calc_mi_estimate,
+GaussianKDE (Q6), the biased in-repo MMD, and -- parity unpinned -- the torch-two-sample MMD against the
+NumPy restatement of its algorithm."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import oracle_np as onp
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def close(a, b, rtol=1e-4, atol=1e-4):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("case", ["generic", "d64", "d20", "collapsed", "peaked"])
+def test_kl_divergence(case):
+    from lvae import estimators as E
+    g = load_golden("logqz_" + case)
+    mu, lv = dev(g["mu"]), dev(g["logvar"])
+    for lam in (0.0, 0.5):
+        kl, hk = E.kl_divergence(mu, lv, lam)
+        close(kl, g[f"kl_lam{lam}"]); close(hk, g[f"hinge_kl_lam{lam}"])
+        kl, hk = E.kl_divergence(mu, lv, lam, average_batch=False)
+        close(kl, g[f"kl_rows_lam{lam}"], atol=1e-3); close(hk, g[f"hinge_kl_rows_lam{lam}"], atol=1e-3)
+        kl, hk = E.kl_divergence(mu, lv, lam, average_batch=False, sum_latent=False)
+        close(kl, g[f"kl_elem_lam{lam}"], atol=1e-4)
+        amb = np.abs(g[f"kl_elem_lam{lam}"] - lam) < 1e-5     # float ties at the hinge threshold
+        close(np.where(amb, 0, hk.cpu().numpy()), np.where(amb, 0, g[f"hinge_kl_elem_lam{lam}"]), atol=1e-4)
+        kl, hk = E.kl_divergence(mu, lv, lam, average_batch=True, sum_latent=False)
+        close(kl, g[f"kl_elem_lam{lam}"].mean(0), atol=1e-4)
+
+
+@pytest.mark.parametrize("case", ["k128", "k16"])
+def test_mi_bounds(case):
+    from lvae import mutual_information as MI
+    g = load_golden("mi_bounds_" + case)
+    z, mulv = dev(g["z"]), dev(g["mu_logvars"])
+    lower, upper = MI.calc_upper_and_lower_bound_representational_mi(z, mulv)
+    assert abs(lower - float(g["lower"])) <= 1e-4 * abs(float(g["lower"]))
+    assert abs(upper - float(g["upper"])) <= 1e-4 * abs(float(g["upper"]))
+    D = g["mu_logvars"].shape[1] // 2
+    mu, std = mulv[:, :D].contiguous(), torch.exp(0.5 * mulv[:, D:]).contiguous()
+    P = MI.log_prob_pairs((mu, std), z)
+    close(P, g["log_prob_pairs"], rtol=1e-4, atol=2e-3)
+    assert abs(MI.mi_lower_bound(z, (mu, std)) - float(g["lower"])) <= 1e-4 * abs(float(g["lower"]))
+    assert abs(MI.mi_upper_bound(z, (mu, std)) - float(g["upper"])) <= 1e-4 * abs(float(g["upper"]))
+    # the reference's own calling convention: a list of torch distributions
+    dists = [torch.distributions.MultivariateNormal(mu[i], torch.diag(std[i])) for i in range(min(8, len(mu)))]
+    P8 = MI.log_prob_pairs(dists, z)
+    close(P8, g["log_prob_pairs"][:len(dists)], rtol=1e-4, atol=2e-3)
+    assert lower <= np.log(len(g["z"])) + 1e-5      # InfoNCE <= log K (float32 rounding slack)
+
+
+def test_mi_bounds_large_vs_oracle():
+    from lvae import mutual_information as MI
+    rng = np.random.default_rng(3)
+    K, D = 1500, 32
+    mu = rng.standard_normal((K, D)).astype(np.float32)
+    lv = (0.5 * rng.standard_normal((K, D)) - 1).astype(np.float32)
+    z = (mu + rng.standard_normal((K, D)).astype(np.float32) * np.exp(0.25 * lv)).astype(np.float32)
+    lo, up = onp.calc_upper_and_lower_bound_representational_mi(z, np.concatenate([mu, lv], 1))
+    glo, gup = MI.calc_upper_and_lower_bound_representational_mi(dev(z), dev(np.concatenate([mu, lv], 1)))
+    assert abs(glo - lo) <= 1e-4 * abs(lo) and abs(gup - up) <= 1e-4 * abs(up)
+
+
+def test_q_z_estimate_gll_calc_mi():
+    from lvae import mutual_information as MI
+    g = load_golden("qz_estimate")
+    z, mu, var = dev(g["z"]), dev(g["mu"]), dev(g["var"])
+    q = MI.q_z_estimate(z, mu, var)
+    assert tuple(q.shape) == g["q_z_estimate"].shape == (1, g["mu"].shape[0])     # Q2
+    close(q, g["q_z_estimate"], rtol=1e-4, atol=2e-3)
+    one = torch.tensor([[1.]]).cuda()
+    close(MI._gaussian_log_likelihood(z.unsqueeze(1), one, 2, mu=mu, var=var), g["gll_full"], atol=2e-3)
+    close(MI._gaussian_log_likelihood(z.unsqueeze(1), one, 2, mu=None, var=var), g["gll_nomu"], atol=2e-3)
+    close(MI._gaussian_log_likelihood(z.unsqueeze(1), one, 2, mu=mu, var=None), g["gll_novar"], atol=2e-3)
+    close(MI._gaussian_log_likelihood(z.unsqueeze(1), one, 2), g["gll_std"], atol=2e-3)
+    for m in ("zhao", "hoffman"):
+        mi, mkl = MI.calc_mi_estimate(dev(g["cme_log_q_z_x"]), None, None, None, dev(g["cme_log_p_z"]),
+                                      float(g["cme_avg_kl"]), mi_method=m)
+        assert abs(mi - float(g[f"cme_mi_{m}"])) <= 1e-4 * abs(float(g[f"cme_mi_{m}"]))
+        assert abs(mkl - float(g[f"cme_marg_kl_{m}"])) <= 1e-4 * abs(float(g[f"cme_marg_kl_{m}"]))
+
+
+def test_kde():
+    from lvae import estimators as E
+    from lvae.kde import GaussianKDE
+    g = load_golden("kde")
+    lat = dev(g["latents"])
+    flat = lat.reshape(-1, 1)
+    k = GaussianKDE(X=flat, bw="scott")
+    assert abs(k.bw - float(g["bw_scott_1d"])) < 1e-12
+    close(k.score_samples(flat), g["score_1d_scott"], atol=1e-4)
+    k2 = GaussianKDE(X=flat, bw=0.25)
+    s = k2.score_samples(dev(g["Y_1d"])).cpu().numpy()
+    assert np.isneginf(s[-3:]).all()                                   # Q6
+    close(s[:-3], g["score_1d_bw025"][:-3], atol=1e-4)
+    k3 = GaussianKDE(X=dev(g["X3"]), bw="scott")
+    close(k3.score_samples(dev(g["Y3"])), g["score_3d_scott"], atol=1e-4)
+    got = E.get_1d_kde_dim_marg_kl_estimate(lat, dev(g["log_p_z_mean"]))
+    assert abs(float(got) - float(g["kde1d_dim_marg_kl"])) <= 1e-4 * abs(float(g["kde1d_dim_marg_kl"]))
+
+
+@pytest.mark.parametrize("case", ["n256", "n100_d64"])
+def test_biased_mmd(case):
+    from lvae import estimators as E
+    g = load_golden("mmd_" + case)
+    x, y = dev(g["x"]), dev(g["y"])
+    m = g["kxy_block"].shape[0]
+    close(E.gaussian_kernel(x[:m], y[:m]), g["kxy_block"], atol=1e-6)
+    n = x.shape[0]
+    out = E.mmd_rbf(x, y, [1.0 / x.shape[1] ** 2], 0.0, unbiased=False).cpu().numpy()
+    # component means at 1e-6; the statistic is a difference of O(1) means: absolute tolerance
+    # against the component magnitude
+    close(out[1] / n ** 2, g["kxx_mean"], atol=2e-6)
+    close(out[2] / n ** 2, g["kyy_mean"], atol=2e-6)
+    close(out[3] / n ** 2, g["kxy_mean"], atol=2e-6)
+    close(E.maximum_mean_discrepancy(y, x), g["mmd"], rtol=0, atol=2e-6)
+    ref64 = onp.maximum_mean_discrepancy(g["y"], g["x"])
+    assert abs(out[0] - ref64) <= 1e-4 * abs(ref64) + 1e-7
+
+
+@pytest.mark.parametrize("n1,n2,D", [(300, 300, 32), (257, 190, 64), (1000, 1200, 32)])
+def test_tts_mmd_unpinned(n1, n2, D):
+    """torch-two-sample is absent from the reference tree: PARITY UNPINNED.  Checked against the float64
+    NumPy restatement of its published algorithm (oracle_np.mmd_statistic_tts)."""
+    from lvae.two_sample import MMDStatistic
+    rng = np.random.default_rng(n1 + D)
+    a = rng.standard_normal((n1, D)).astype(np.float32)
+    b = (rng.standard_normal((n2, D)) * 0.8 + 0.3).astype(np.float32)
+    alphas = [0.1 * i for i in range(15)]
+    ref, K = onp.mmd_statistic_tts(a, b, alphas, ret_matrix=True)
+    got = float(MMDStatistic(n1, n2)(dev(a), dev(b), alphas))
+    assert abs(got - ref) <= 1e-4 * abs(ref)
+    if n1 <= 300:
+        got2, Kg = MMDStatistic(n1, n2)(dev(a), dev(b), alphas, ret_matrix=True)
+        close(Kg, K, rtol=1e-4, atol=1e-5)
+    # non-multiple bandwidths take the general (one exp per bandwidth) epilogue
+    al2 = [0.05, 0.13, 0.31]
+    ref2 = onp.mmd_statistic_tts(a, b, al2)
+    got2 = float(MMDStatistic(n1, n2)(dev(a), dev(b), al2))
+    assert abs(got2 - ref2) <= 1e-4 * abs(ref2)
+    # same distribution: statistic ~ 0 (may be slightly negative), error judged against the kernel scale
+    c = rng.standard_normal((n2, D)).astype(np.float32)
+    ref3 = onp.mmd_statistic_tts(a, c, alphas)
+    got3 = float(MMDStatistic(n1, n2)(dev(a), dev(c), alphas))
+    assert abs(got3 - ref3) <= 2e-6 * 15
+
+
+def test_get_tts_mmmd_and_encode_tail():
+    from lvae import encoder_ops as EO
+    from lvae import estimators as E
+    g = load_golden("iw_k37_d64")
+    mu, lv, eps = dev(g["mu"]), dev(g["logvar"]), dev(g["eps"])
+    z = EO.reparameterize(mu, lv, n_samples=eps.shape[1], eps=eps)
+    close(z, g["z"], rtol=1e-6, atol=1e-6)
+    assert tuple(EO.reparameterize(mu, lv, n_samples=3).shape) == (mu.shape[0], 3, mu.shape[1])
+    assert tuple(EO.sample_from_prior(32, 5, "cuda:0").shape) == (5, 32)
+    out = EO.encode_tail(mu, lv, n_samples=eps.shape[1], eps=eps)
+    close(out["log_q_z_x"], g["log_q_z_x"], atol=1e-3)
+    close(out["log_p_z"], g["log_p_z"], atol=1e-3)
+    ref_lq, ref_pm = onp.approximate_log_q_z(g["mu"], g["logvar"], g["z"][:, 0], "chen", 10000, True, True)
+    assert abs(float(out["log_q_z"]) - ref_lq) <= 1e-4 * abs(ref_lq)
+    assert abs(float(out["log_q_z_prod_marg"]) - ref_pm) <= 1e-4 * abs(ref_pm)
+    prior = torch.randn(mu.shape[0], mu.shape[1], device="cuda")
+    t = E.get_tts_mmmd(z[:, :1, :], prior)
+    ref = onp.mmd_statistic_tts(g["z"][:, 0], prior.cpu().numpy(), [0.1 * i for i in range(15)])
+    assert abs(float(t) - ref) <= 1e-4 * abs(ref) + 1e-5
+    # the intended marginal KL and the reference's raising behaviour (Q1)
+    kl = E.approximate_marginal_KL(mu, lv, z[:, 0].contiguous(), "chen", 10000)
+    ref_kl = onp.approximate_marginal_KL_intended(g["mu"], g["logvar"], g["z"][:, 0], "chen", 10000)
+    assert abs(float(kl) - ref_kl) <= 1e-4 * abs(ref_kl)
+    with pytest.raises(AttributeError):
+        E.approximate_marginal_KL(mu, lv, z[:, 0].contiguous(), "chen", 10000, strict=True)
+    tc = E.approximate_total_correlation(mu, lv, z[:, 0].contiguous(), "chen", 10000)
+    assert abs(float(tc) - (ref_lq - ref_pm)) <= 1e-4 * abs(ref_lq - ref_pm) + 1e-3
