@@ -88,10 +88,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # LVAE_BENCH_REHEARSAL=1: several ranks on one GPU, to rehearse the multi-rank code path on a
+    # single-GPU box (never used by the driver; numbers from it mean nothing)
+    rehearsal = os.environ.get("LVAE_BENCH_REHEARSAL") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from lvae import _native as N
     from lvae import distributed as LD
@@ -104,7 +111,8 @@ def main():
 
     def step():
         if world > 1:
-            state["out"] = LD.sharded_latent_stats(mu, logvar, z, method="all")
+            state["out"] = LD.sharded_latent_stats(mu, logvar, z, method="all",
+                                                   counts=[n_total // world] * world)
         else:
             sums, lq = LD.hip_local_stats(mu, logvar, z, mu, logvar, log_norm, False)
             s_lq, _, s_lp, s_lqx, cnt = sums.tolist()
@@ -130,7 +138,7 @@ def main():
     k_ms, k_n = ctypes.c_double(0), ctypes.c_int(0)
     N.check(N.lib().lvae_profile_end(ctypes.byref(k_ms), ctypes.byref(k_n)))
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -28,23 +28,52 @@ def shard_bounds(n, world_size, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def all_gather_rows(x, group=None):
+def _host_staged(group):
+    """gloo has no device collectives: with that backend GPU tensors are staged through host memory
+    (debug / rehearsal only; RCCL works on device memory directly)."""
+    return dist.get_backend(group) == "gloo"
+
+
+def _all_gather_into(out, x, group):
+    if x.is_cuda and _host_staged(group):
+        tmp = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(tmp, x.cpu(), group=group)
+        out.copy_(tmp)
+    else:
+        dist.all_gather_into_tensor(out, x, group=group)
+
+
+def _all_reduce(x, op, group):
+    if x.is_cuda and _host_staged(group):
+        tmp = x.cpu()
+        dist.all_reduce(tmp, op=op, group=group)
+        x.copy_(tmp)
+    else:
+        dist.all_reduce(x, op=op, group=group)
+
+
+def all_gather_rows(x, group=None, counts=None):
     """All-gather a [n_r, C] tensor whose row count may differ per rank -> [sum n_r, C], plus the row
-    offset of every rank."""
+    offset of every rank.  ``counts`` (rows per rank), when the caller knows them, saves the size
+    exchange and its host synchronisation."""
     ws = dist.get_world_size(group)
-    n_local = torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device)
-    counts = torch.empty(ws, dtype=torch.int64, device=x.device)
-    dist.all_gather_into_tensor(counts, n_local, group=group)
-    counts = counts.tolist()
+    if counts is None:
+        n_local = torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device)
+        counts = torch.empty(ws, dtype=torch.int64, device=x.device)
+        _all_gather_into(counts, n_local, group)
+        counts = counts.tolist()
+    else:
+        counts = [int(c) for c in counts]
+        assert len(counts) == ws and counts[dist.get_rank(group)] == x.shape[0]
     nmax = max(counts)
     if all(c == nmax for c in counts):
         out = torch.empty((ws * nmax,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+        _all_gather_into(out, x.contiguous(), group)
     else:
         pad = torch.zeros((nmax,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         pad[:x.shape[0]] = x
         buf = torch.empty((ws * nmax,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(buf, pad, group=group)
+        _all_gather_into(buf, pad, group)
         out = torch.cat([buf[r * nmax:r * nmax + counts[r]] for r in range(ws)], dim=0)
     offsets = [0]
     for c in counts:
@@ -69,16 +98,17 @@ def hip_local_stats(mu_all, logvar_all, z_local, mu_local, logvar_local, log_nor
 
 
 def sharded_latent_stats(mu_local, logvar_local, z_local, method="all", dataset_size=None,
-                         prod_marginals=False, group=None, local_stats=hip_local_stats):
+                         prod_marginals=False, group=None, local_stats=hip_local_stats, counts=None):
     """Marginal KL / MI (/ TC, dimension-wise KL) over posteriors and samples sharded by rows.
 
     mu_local, logvar_local, z_local: this rank's [n_r, D] rows (z_i drawn from posterior i).
     Returns a dict of Python floats identical on every rank, with the definitions of
     loss_and_optimisation.py:816-824: mi = E[log q(z|x)] - E[log q(z)], marginal_kl = E[log q(z)] -
     E[log p(z)], tc = E[log q(z)] - E[log prod q(z_d)], dim_kl = E[log prod q(z_d)] - E[log p(z)];
-    plus ``log_q_z_local`` (this rank's per-sample vector, left sharded)."""
+    plus ``log_q_z_local`` (this rank's per-sample vector, left sharded).  ``counts``: rows per rank if
+    known (skips the size exchange)."""
     packed = torch.cat([mu_local, logvar_local], dim=1).contiguous()
-    gathered, _ = all_gather_rows(packed, group)
+    gathered, _ = all_gather_rows(packed, group, counts)
     D = mu_local.shape[1]
     mu_all, logvar_all = gathered[:, :D].contiguous(), gathered[:, D:].contiguous()
     n_total = mu_all.shape[0]
@@ -90,7 +120,7 @@ def sharded_latent_stats(mu_local, logvar_local, z_local, method="all", dataset_
     sums, log_q_z = local_stats(mu_all, logvar_all, z_local, mu_local, logvar_local, log_norm,
                                 prod_marginals)
     sums = sums.to(torch.float64).contiguous()
-    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce(sums, dist.ReduceOp.SUM, group)
     s_lq, s_pm, s_lp, s_lqx, cnt = sums.tolist()
     out = {
         "n_total": int(n_total), "m_total": int(round(cnt)),
@@ -119,7 +149,7 @@ def combine_partial_lse(row_max, row_sum, log_norm, group=None):
     """Column-sharded alternative: every rank holds ALL z rows but only its posteriors and has produced
     (row_max, row_sum) with lvae_log_qz_partial_f32.  all-reduce(max), rescale, all-reduce(sum)."""
     gmax = row_max.clone()
-    dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
+    _all_reduce(gmax, dist.ReduceOp.MAX, group)
     scaled = row_sum.double() * torch.exp(row_max.double() - gmax.double())
-    dist.all_reduce(scaled, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce(scaled, dist.ReduceOp.SUM, group)
     return (gmax.double() + torch.log(scaled) - log_norm).float()
