@@ -26,9 +26,12 @@ __device__ __forceinline__ void lse_push(float& m, float& s, float w) {
     }
 }
 
-// MODE_EPS: the row source is eps (z is computed); otherwise the row source is z itself.
-// One workgroup per sentence b; G lanes per sample row (G = D/4, power of two <= 64).
-template <bool FROM_EPS>
+// FROM_EPS: the row source is eps (z is computed); otherwise the row source is z itself.
+// One workgroup per sentence b; G = D/4 lanes per sample row (power of two <= 64).  Every lane group
+// keeps U consecutive rows in flight (U independent 16-B loads per lane); after the shuffle reduction
+// lane u of the group owns row u's densities, so the [B,K] outputs and log_p_x_z move as runs of
+// consecutive floats (U per group, 64*U/G per wave-instruction) instead of one float per group.
+template <bool FROM_EPS, int U>
 __global__ void __launch_bounds__(256)
 sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
                  const float* __restrict__ src, const float* __restrict__ log_p_x_z, int64_t K, int D,
@@ -36,8 +39,8 @@ sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
                  float* __restrict__ log_p_z, float* __restrict__ iw_ll) {
     const int64_t b = blockIdx.x;
     const int gl = threadIdx.x % G;          // lane inside the row group: owns dims 4*gl .. 4*gl+3
-    const int row_in_blk = threadIdx.x / G;
-    const int rows_per_iter = 256 / G;
+    const int grp = threadIdx.x / G;
+    const int rows_per_iter = (256 / G) * U;
     const bool have_post = mu != nullptr;
     f32x4 m4 = {0.f, 0.f, 0.f, 0.f}, lv4 = m4, sd4 = m4, iv4 = m4;
     if (have_post) {
@@ -46,38 +49,51 @@ sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             sd4[e] = expf(0.5f * lv4[e]);
-            iv4[e] = expf(lv4[e]);
+            iv4[e] = 1.0f / expf(lv4[e]);      // 1/var: the streaming loop multiplies instead of dividing
         }
     }
     float lm = -INFINITY, ls = 0.f;
     const float* __restrict__ base = src + b * K * D;
     for (int64_t k0 = 0; k0 < K; k0 += rows_per_iter) {
-        const int64_t k = k0 + row_in_blk;
-        const bool ok = k < K;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) v = *reinterpret_cast<const f32x4*>(base + k * D + 4 * gl);
-        f32x4 zz;
-        float lq = 0.f, lp = 0.f;
+        const int64_t kg = k0 + (int64_t)grp * U;        // first row of this group
+        f32x4 v[U];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            // separate multiply and add, like the reference (no fused contraction)
-            zz[e] = FROM_EPS ? __fadd_rn(m4[e], __fmul_rn(v[e], sd4[e])) : v[e];
-            if (have_post) {
-                const float df = zz[e] - m4[e];
-                lq += -0.5f * (lv4[e] + LVAE_LOG_2PI + __fdiv_rn(df * df, iv4[e]));
-            }
-            lp += -0.5f * (LVAE_LOG_2PI + zz[e] * zz[e]);
+        for (int u = 0; u < U; ++u) {
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kg + u < K) v[u] = *reinterpret_cast<const f32x4*>(base + (kg + u) * D + 4 * gl);
         }
-        if (FROM_EPS && z_out && ok) *reinterpret_cast<f32x4*>(z_out + (b * K + k) * D + 4 * gl) = zz;
-        lq = group_sum(lq, G);
-        lp = group_sum(lp, G);
-        if (ok && gl == 0) {
-            if (log_q_z_x) log_q_z_x[b * K + k] = lq;
-            if (log_p_z) log_p_z[b * K + k] = lp;
-            if (iw_ll) {
-                const float w = (log_p_x_z ? log_p_x_z[b * K + k] : 0.f) + lp - lq;
-                lse_push(lm, ls, w);
+        const int64_t kmine = kg + gl;                   // the row whose results this lane will own
+        const bool mine = gl < U && kmine < K;
+        float pxz = 0.f;
+        if (mine && iw_ll && log_p_x_z) pxz = log_p_x_z[b * K + kmine];
+        float my_lq = 0.f, my_lp = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f32x4 zz;
+            float lq = 0.f, lp = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // separate multiply and add, like the reference (no fused contraction)
+                zz[e] = FROM_EPS ? __fadd_rn(m4[e], __fmul_rn(v[u][e], sd4[e])) : v[u][e];
+                if (have_post) {
+                    const float df = zz[e] - m4[e];
+                    lq += -0.5f * (lv4[e] + LVAE_LOG_2PI + df * df * iv4[e]);
+                }
+                lp += -0.5f * (LVAE_LOG_2PI + zz[e] * zz[e]);
             }
+            if (FROM_EPS && z_out && kg + u < K)
+                *reinterpret_cast<f32x4*>(z_out + (b * K + kg + u) * D + 4 * gl) = zz;
+            lq = group_sum(lq, G);
+            lp = group_sum(lp, G);
+            if (gl == u) {
+                my_lq = lq;
+                my_lp = lp;
+            }
+        }
+        if (mine) {
+            if (log_q_z_x) log_q_z_x[b * K + kmine] = my_lq;
+            if (log_p_z) log_p_z[b * K + kmine] = my_lp;
+            if (iw_ll) lse_push(lm, ls, pxz + my_lp - my_lq);
         }
     }
     if (iw_ll) {
@@ -85,13 +101,18 @@ sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
         sm_m[threadIdx.x] = lm;
         sm_s[threadIdx.x] = ls;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            float mx = -INFINITY;
-            for (int t = 0; t < 256; t += G) mx = fmaxf(mx, sm_m[t]);
-            double s = 0.0;
-            for (int t = 0; t < 256; t += G)
-                if (sm_s[t] > 0.f) s += (double)sm_s[t] * exp((double)sm_m[t] - (double)mx);
-            iw_ll[b] = (float)((double)mx + log(s) - log((double)K));
+        if (threadIdx.x < 64) {
+            float mx = fmaxf(fmaxf(sm_m[threadIdx.x], sm_m[threadIdx.x + 64]),
+                             fmaxf(sm_m[threadIdx.x + 128], sm_m[threadIdx.x + 192]));
+            mx = wave_max(mx);
+            double sacc = 0.0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float sv = sm_s[threadIdx.x + 64 * t];
+                if (sv > 0.f) sacc += (double)sv * exp((double)sm_m[threadIdx.x + 64 * t] - (double)mx);
+            }
+            sacc = wave_sum_d(sacc);
+            if (threadIdx.x == 0) iw_ll[b] = (float)((double)mx + log(sacc) - log((double)K));
         }
     }
 }
@@ -238,12 +259,18 @@ int lvae_launch_sample_iw(bool from_eps, const float* mu, const float* logvar, c
         return LVAE_OK;
     }
     if (vec_ok(D, &G)) {
-        if (from_eps)
-            hipLaunchKernelGGL(sample_iw_kernel<true>, grid, dim3(256), 0, st, mu, logvar, src, log_p_x_z,
-                               K, D, G, z_out, log_q_z_x, log_p_z, iw_ll);
-        else
-            hipLaunchKernelGGL(sample_iw_kernel<false>, grid, dim3(256), 0, st, mu, logvar, src,
-                               log_p_x_z, K, D, G, z_out, log_q_z_x, log_p_z, iw_ll);
+#define LVAE_SIW(E, UU)                                                                             \
+    hipLaunchKernelGGL((sample_iw_kernel<E, UU>), grid, dim3(256), 0, st, mu, logvar, src, log_p_x_z, K, D, \
+                       G, z_out, log_q_z_x, log_p_z, iw_ll)
+        const int U = G < 8 ? G : 8;
+        if (from_eps) {
+            if (U == 8) LVAE_SIW(true, 8); else if (U == 4) LVAE_SIW(true, 4);
+            else if (U == 2) LVAE_SIW(true, 2); else LVAE_SIW(true, 1);
+        } else {
+            if (U == 8) LVAE_SIW(false, 8); else if (U == 4) LVAE_SIW(false, 4);
+            else if (U == 2) LVAE_SIW(false, 2); else LVAE_SIW(false, 1);
+        }
+#undef LVAE_SIW
     } else {
         if (from_eps)
             hipLaunchKernelGGL(sample_iw_generic_kernel<true>, grid, dim3(256), 0, st, mu, logvar, src,
