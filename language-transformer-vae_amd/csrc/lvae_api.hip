@@ -42,7 +42,7 @@ int lvae_launch_latent_sums(const float* z, const float* mu, const float* logvar
 
 int lvae_launch_pair_mfma(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                           float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
-                          bool excl, int64_t excl_offset, bool ksum, hipStream_t st);
+                          bool excl, int64_t excl_offset, int epi, hipStream_t st);
 int lvae_launch_finalize_ksum(const double* partial, int nsplit, int64_t cpad, int64_t C, double* out,
                               hipStream_t st);
 int lvae_launch_kl(const float* mu, const float* logvar, int64_t n, int D, float lambda, float* kl_elem,
@@ -500,7 +500,12 @@ extern "C" int lvae_mmd_workspace_bytes(int64_t n1, int64_t n2, int D, int64_t* 
 }
 
 // Kernel-matrix sum over (kept = a [na], reduced = b [nb]) into *out (float64, device).
-static int ksum_pass(const float* a, int64_t na, const float* b, int64_t nb, int D, bool excl,
+static int ksum_epi(const KsumParams& kp) {
+    if (!kp.poly) return 3;
+    return kp.n <= 1 ? 1 : (kp.n <= 16 ? 2 : 3);
+}
+
+static int ksum_pass(const float* a, int64_t na, const float* b, int64_t nb, int D, bool excl, int epi,
                      void* ws, double* out, hipStream_t st) {
     const PairPlan p = lvae_make_pair_plan(nb, na, D, false);
     char* base = (char*)ws;
@@ -514,7 +519,7 @@ static int ksum_pass(const float* a, int64_t na, const float* b, int64_t nb, int
     if (rc) return rc;
     rc = lvae_launch_prep(1, false, a, nullptr, 0, na, p.cpad, D, p.DP, hdr, 1, cop, nullptr, nullptr, p.DC, st);
     if (rc) return rc;
-    rc = lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, -1.f, 0, excl, 0, true, st);
+    rc = lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, -1.f, 0, excl, 0, epi, st);
     if (rc) return rc;
     return lvae_launch_finalize_ksum((const double*)partial, p.nsplit, p.cpad, na, out, st);
 }
@@ -544,11 +549,12 @@ extern "C" int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int6
     if (kp.n == 0 && kp.c[0] == 0.f) {
         LVAE_HIP(hipMemsetAsync(sums, 0, 3 * sizeof(double), st));
     } else {
-        rc = ksum_pass(x, n1, x, n1, D, excl, ws, sums + 0, st);
+        const int epi = ksum_epi(kp);
+        rc = ksum_pass(x, n1, x, n1, D, excl, epi, ws, sums + 0, st);
         if (rc) return rc;
-        rc = ksum_pass(y, n2, y, n2, D, excl, ws, sums + 1, st);
+        rc = ksum_pass(y, n2, y, n2, D, excl, epi, ws, sums + 1, st);
         if (rc) return rc;
-        rc = ksum_pass(x, n1, y, n2, D, false, ws, sums + 2, st);
+        rc = ksum_pass(x, n1, y, n2, D, false, epi, ws, sums + 2, st);
         if (rc) return rc;
     }
     return lvae_launch_mmd_stat(sums, n1, n2, unbiased, zeros, out, st);

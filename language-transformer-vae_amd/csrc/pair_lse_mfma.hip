@@ -152,7 +152,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (want == 8 * g + 4 * h + e) acc[cb][4 * g + e] = EPI == 1 ? INFINITY : -INFINITY;
+                        if (want == 8 * g + 4 * h + e) acc[cb][4 * g + e] = EPI >= 1 ? INFINITY : -INFINITY;
             }
         }
     };
@@ -162,24 +162,43 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     //   0: max of elements 0..7        1: max of 8..15, lazy rescale of the running (max, sum)
     //   2..9: two exponentials each, added to the running sum.
     // (EPI 1: 17 micro-slices: one pair each, the last one folds the tile sum into float64.)
-    constexpr int EPI_MS = EPI == 1 ? 17 : 10;
+    constexpr int EPI_MS = EPI >= 1 ? 17 : 10;
     float tmax[NCB];
-    const KsumParams* __restrict__ kp = &hdr->ksum;     // wave-uniform: scalar loads
+    // Kernel-sum parameters, read once into (scalar) registers: EPI 1 = one bandwidth (c0 + c1*t),
+    // EPI 2 = polynomial of degree <= 16 in t, fully unrolled Horner (unused high coefficients are 0),
+    // EPI 3 = arbitrary bandwidths, one exponential each.
+    constexpr int KC = EPI == 1 ? 2 : (EPI == 2 ? 17 : (EPI == 3 ? LVAE_KSUM_MAX : 1));
+    float kc[KC];
+    float k_eps = 0.f, k_nbase = 0.f;
+    int k_n = 0;
+    if (EPI >= 1) {
+        const KsumParams* kp = &hdr->ksum;
+        k_eps = kp->eps;
+        k_nbase = kp->nbase;
+        k_n = kp->n;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) kc[k] = kp->c[k];
+    }
     auto kfun = [&](float d2) -> float {
-        const float v = fabsf(d2) + kp->eps;
-        const int n = kp->n;
-        if (kp->poly) {
-            const float t = lvae_exp2(v * kp->nbase);
-            float pacc = kp->c[n];
-            for (int k = n - 1; k >= 0; --k) pacc = fmaf(pacc, t, kp->c[k]);
+        const float v = fabsf(d2) + k_eps;
+        if (EPI == 1) {
+            return fmaf(kc[1], lvae_exp2(v * k_nbase), kc[0]);
+        } else if (EPI == 2) {
+            const float t = lvae_exp2(v * k_nbase);
+            float pacc = kc[16];
+#pragma unroll
+            for (int k = 15; k >= 0; --k) pacc = fmaf(pacc, t, kc[k]);
             return pacc;
+        } else {
+            float f = 0.f;
+#pragma unroll 4
+            for (int k = 0; k < KC; ++k)
+                if (k < k_n) f += lvae_exp2(v * kc[k]);
+            return f;
         }
-        float f = 0.f;
-        for (int k = 0; k < n; ++k) f += lvae_exp2(v * kp->c[k]);
-        return f;
     };
     auto epi_micro = [&](const f32x16 (&prev)[NCB], int cb, int ms) {
-        if (EPI == 1) {
+        if (EPI >= 1) {
             if (ms < 16) {
                 kt[cb] += kfun(prev[cb][ms]);
             } else {
@@ -318,7 +337,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     }
 
     // merge the two half-waves (same column, complementary rows) and publish
-    if (EPI == 1) {
+    if (EPI >= 1) {
         double* kpartial = reinterpret_cast<double*>(partial);
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
@@ -340,18 +359,22 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
 template <int DP, int NCB, int WPS>
 static int launch_t(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                     float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
-                    bool excl, int64_t excl_offset, bool ksum, hipStream_t st) {
+                    bool excl, int64_t excl_offset, int epi, hipStream_t st) {
     const dim3 grid((unsigned)(p.cpad / (4 * 32 * NCB)), (unsigned)p.nsplit);
 #define LVAE_PAIR(X, E)                                                                              \
     hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, NCB, WPS, X, E>), grid, dim3(256), 0, st, rfrag, rbias, \
                        cop, partial, hdr, cond_limit, use_if_above, p.nblk, p.blk_per_split, p.cpad,  \
                        excl_offset)
-    if (ksum) {
-        if (excl) LVAE_PAIR(true, 1);
-        else LVAE_PAIR(false, 1);
-    } else {
-        if (excl) LVAE_PAIR(true, 0);
-        else LVAE_PAIR(false, 0);
+    switch (epi * 2 + (excl ? 1 : 0)) {
+        case 0: LVAE_PAIR(false, 0); break;
+        case 1: LVAE_PAIR(true, 0); break;
+        case 2: LVAE_PAIR(false, 1); break;
+        case 3: LVAE_PAIR(true, 1); break;
+        case 4: LVAE_PAIR(false, 2); break;
+        case 5: LVAE_PAIR(true, 2); break;
+        case 6: LVAE_PAIR(false, 3); break;
+        case 7: LVAE_PAIR(true, 3); break;
+        default: return lvae_set_error(LVAE_ERR_INVALID, "bad epilogue id %d", epi);
     }
 #undef LVAE_PAIR
     LVAE_LAUNCH_CHECK();
@@ -359,19 +382,19 @@ static int launch_t(const PairPlan& p, const float* rfrag, const float* rbias, c
 }
 
 // cond_limit < 0: run unconditionally.  Otherwise run iff (cond > cond_limit) == use_if_above.
-// ksum == false: logsumexp epilogue; true: kernel-matrix column sums (float64 partials; parameters in
-// hdr->ksum).
+// epi 0: logsumexp epilogue; 1/2/3: kernel-matrix column sums (float64 partials; parameters in
+// hdr->ksum: single bandwidth / polynomial of degree <= 16 / arbitrary bandwidths).
 int lvae_launch_pair_mfma(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                           float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
-                          bool excl, int64_t excl_offset, bool ksum, hipStream_t st) {
+                          bool excl, int64_t excl_offset, int epi, hipStream_t st) {
     if (p.cpad % (4 * 32 * p.NCB) != 0)
         return lvae_set_error(LVAE_ERR_INVALID, "pair plan: cpad %lld not a multiple of the tile",
                               (long long)p.cpad);
     switch (p.DP) {
-        case 16: return launch_t<16, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, ksum, st);
-        case 32: return launch_t<32, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, ksum, st);
-        case 64: return launch_t<64, 1, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, ksum, st);
-        case 128: return launch_t<128, 1, 1>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, ksum, st);
+        case 16: return launch_t<16, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, st);
+        case 32: return launch_t<32, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, st);
+        case 64: return launch_t<64, 1, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, st);
+        case 128: return launch_t<128, 1, 1>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, st);
         default:
             return lvae_set_error(LVAE_ERR_UNSUPPORTED, "MFMA path needs D <= 128 (got D=%d)", p.D);
     }
@@ -382,5 +405,5 @@ int lvae_launch_pair_lse_mfma(const PairPlan& p, const float* rfrag, const float
                               float cond_limit, int use_if_above, bool excl, int64_t excl_offset,
                               hipStream_t st) {
     return lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl,
-                                 excl_offset, false, st);
+                                 excl_offset, 0, st);
 }
