@@ -23,7 +23,7 @@ int lvae_launch_pair_lse_mfma(const PairPlan& p, const float* rfrag, const float
                               float cond_limit, int use_if_above, bool excl, int64_t excl_offset,
                               hipStream_t st);
 int lvae_launch_pair_direct(const PairPlan& p, bool joint, bool pm, const float* z,
-                            const float* dparams, float2* partial, float2* partial_pm,
+                            const float* dparams, float2* partial, float2* partial_pm, int* redo_flags,
                             const PairHeader* hdr, float cond_limit, int use_if_above, int excl,
                             int64_t excl_offset, hipStream_t st);
 
@@ -195,11 +195,10 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     float2* dpartial_pm = (float2*)(base + p.off_dpartial_pm);
     const bool want_joint = log_qz || row_max;
 
-    // With prod-marginals requested the direct kernel visits every (i,j,d) term anyway and the joint
-    // density rides along for one add per term, so the MFMA kernel is only used when asked for.
+    // The prod-marginals sweep is a kernel of its own (packed fp32 VALU + one exponential per term);
+    // the joint density goes through the MFMA kernel as usual, which costs a fraction of that sweep.
     int joint_path = path;
     if (p.DP == 0) joint_path = LVAE_PATH_DIRECT;
-    else if (with_pm && path == LVAE_PATH_AUTO) joint_path = LVAE_PATH_DIRECT;
     const bool need_mfma = want_joint && joint_path != LVAE_PATH_DIRECT;
     const bool need_direct = with_pm || (want_joint && joint_path != LVAE_PATH_MFMA);
 
@@ -230,7 +229,8 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     }
     if (need_direct) {
         const bool djoint = want_joint && joint_path != LVAE_PATH_MFMA;
-        rc = lvae_launch_pair_direct(p, djoint, with_pm, z, dparams, dpartial, dpartial_pm, hdr, limit, 1,
+        rc = lvae_launch_pair_direct(p, djoint, with_pm, z, dparams, dpartial, dpartial_pm,
+                                     (int*)(base + p.off_dflags), hdr, limit, 1,
                                      exclude_diag, diag_offset, st);
         if (rc) return rc;
     }

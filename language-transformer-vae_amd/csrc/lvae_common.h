@@ -11,6 +11,7 @@
 #define LVAE_LOG_2PI 1.8378770664093453f
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---- error plumbing (lvae_api.hip owns the storage) -------------------------------------------

@@ -4,8 +4,8 @@
 // wave-uniform, so its parameters (mu_j, w_j = sqrt(0.5*log2e/var_j), b_j = -0.5*log2e*(log var_j +
 // log 2pi)) are read through uniform loads shared by the whole wave.  Per (i, j, d):
 //     y = (z_id - mu_jd) * w_jd ;  t = b_jd - y*y            (base-2 log-density of one dimension)
-// JOINT : v_ij = sum_d t, folded into the lane's running (max, sum)        -> log q(z_i)
-// PM    : every (i, d) keeps its own running (max, sum) over j             -> prod-of-marginals term
+// joint : v_ij = sum_d t, folded into the lane's running (max, sum)        -> log q(z_i)
+// pm    : every (i, d) keeps its own sum over j                            -> prod-of-marginals term
 //         (loss_and_optimisation.py:195: logsumexp of the [M,N,D] tensor over the posterior axis).
 // This form has no cancellation (it is the reference's own formula), so it also serves as the
 // fall-back of the MFMA path for badly conditioned inputs (peaked posteriors far from the origin) and
@@ -16,13 +16,12 @@
 #define DLSE_THR 8.0f
 #define DLSE_MINIT (-1.0e30f)
 
-template <int DCT, bool JOINT, bool PM>
+template <int DCT>
 __global__ void __launch_bounds__(256)
 pair_direct_kernel(const float* __restrict__ z, const float* __restrict__ dparams,
-                   float2* __restrict__ partial, float2* __restrict__ partial_pm,
-                   const PairHeader* __restrict__ hdr, float cond_limit, int use_if_above,
-                   int64_t C, int64_t cpad, int64_t R, int64_t rows_per_split, int D, int DC, int d0,
-                   int excl, int64_t excl_offset) {
+                   float2* __restrict__ partial, const PairHeader* __restrict__ hdr, float cond_limit,
+                   int use_if_above, int64_t C, int64_t cpad, int64_t R, int64_t rows_per_split, int D,
+                   int DC, int excl, int64_t excl_offset) {
     if (cond_limit >= 0.f) {
         const float cond = __uint_as_float(hdr->cond_bits);
         if ((cond > cond_limit) != (use_if_above != 0)) return;
@@ -32,86 +31,164 @@ pair_direct_kernel(const float* __restrict__ z, const float* __restrict__ dparam
 
     float zr[DCT];
 #pragma unroll
-    for (int d = 0; d < DCT; ++d) zr[d] = (d0 + d < D) ? z[i * D + d0 + d] : 0.f;
+    for (int d = 0; d < DCT; ++d) zr[d] = d < D ? z[i * D + d] : 0.f;
 
     float mv = DLSE_MINIT, sv = 0.f;
-    float m[PM ? DCT : 1], s[PM ? DCT : 1];
-    if (PM) {
-#pragma unroll
-        for (int d = 0; d < DCT; ++d) {
-            m[d] = DLSE_MINIT;
-            s[d] = 0.f;
-        }
-    }
-
     const int64_t j0 = (int64_t)blockIdx.y * rows_per_split;
     int64_t j1 = j0 + rows_per_split;
     if (j1 > R) j1 = R;
     const int64_t jskip = excl ? i + excl_offset : -1;
 
     for (int64_t j = j0; j < j1; ++j) {
-        const float* __restrict__ pm = dparams + (j * 3 + 0) * DC + d0;
-        const float* __restrict__ pw = dparams + (j * 3 + 1) * DC + d0;
-        const float* __restrict__ pb = dparams + (j * 3 + 2) * DC + d0;
+        const float* __restrict__ pm = dparams + (j * 3 + 0) * DC;
+        const float* __restrict__ pw = dparams + (j * 3 + 1) * DC;
+        const float* __restrict__ pb = dparams + (j * 3 + 2) * DC;
         float v = 0.f;
 #pragma unroll
-        for (int g = 0; g < DCT; g += 16) {
-            float t16[16];
-            float ex = -INFINITY;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int d = g + e;
-                const float y = (zr[d] - pm[d]) * pw[d];
-                const float t = fmaf(-y, y, pb[d]);
-                if (JOINT) v += t;
-                if (PM) {
-                    t16[e] = t;
-                    ex = fmaxf(ex, t - m[d]);
-                }
-            }
-            if (PM) {
-                if (__any(ex > DLSE_THR)) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int d = g + e;
-                        const float x = t16[e] - m[d];
-                        if (x > DLSE_THR) {
-                            s[d] = s[d] * lvae_exp2(-x) + 1.0f;
-                            m[d] = t16[e];
-                        } else {
-                            s[d] += lvae_exp2(x);
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) s[g + e] += lvae_exp2(t16[e] - m[g + e]);
-                }
-            }
+        for (int d = 0; d < DCT; ++d) {
+            const float y = (zr[d] - pm[d]) * pw[d];
+            v += fmaf(-y, y, pb[d]);
         }
-        if (JOINT) {
-            if (j == jskip) v = -INFINITY;
-            const float xv = v - mv;
-            if (__any(xv > DLSE_THR)) {
-                if (xv > DLSE_THR) {
-                    sv = sv * lvae_exp2(-xv) + 1.0f;
-                    mv = v;
-                } else {
-                    sv += lvae_exp2(xv);
-                }
+        if (j == jskip) v = -INFINITY;
+        const float xv = v - mv;
+        if (__any(xv > DLSE_THR)) {
+            if (xv > DLSE_THR) {
+                sv = sv * lvae_exp2(-xv) + 1.0f;
+                mv = v;
             } else {
                 sv += lvae_exp2(xv);
             }
+        } else {
+            sv += lvae_exp2(xv);
         }
     }
+    if (col < C) partial[(int64_t)blockIdx.y * cpad + col] = make_float2(mv, sv);
+}
 
-    if (col < C) {
-        if (JOINT) partial[(int64_t)blockIdx.y * cpad + col] = make_float2(mv, sv);
-        if (PM) {
+// Product-of-marginals sweep: every (sample i, dimension d) keeps its own sum over the posteriors j of
+// exp2(t_ijd).  Fast pass: reference 0 (t <= b_jd = -0.5*log2(2 pi var), a few bits either side of 0
+// for any sane variance), two dimensions per packed fp32 instruction -- per term 2.5 VALU slots and one
+// v_exp_f32.  A wave in which any sum left the range [2^-60, 2^100] (a sample ~9 sigma away from every
+// posterior of the split, or absurd variances) raises its redo flag instead of storing, and
+// pair_pm_online_kernel repeats that wave's sweep with the running-maximum form.
+#define PM_SUM_MIN 8.6736174e-19f   // 2^-60
+#define PM_SUM_MAX 1.2676506e30f    // 2^100
+template <int DCT>
+__global__ void __launch_bounds__(256)
+pair_pm_kernel(const float* __restrict__ z, const float* __restrict__ dparams,
+               float2* __restrict__ partial_pm, int* __restrict__ redo_flags, int64_t C, int64_t cpad,
+               int64_t R, int64_t rows_per_split, int D, int DC, int d0) {
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = col < C ? col : C - 1;
+    const int64_t j0 = (int64_t)blockIdx.y * rows_per_split;
+    int64_t j1 = j0 + rows_per_split;
+    if (j1 > R) j1 = R;
+
+    f32x2 zr[DCT / 2], s2[DCT / 2];
 #pragma unroll
-            for (int d = 0; d < DCT; ++d)
-                if (d0 + d < DC)
-                    partial_pm[((int64_t)blockIdx.y * DC + d0 + d) * cpad + col] = make_float2(m[d], s[d]);
+    for (int h = 0; h < DCT / 2; ++h) {
+        zr[h].x = (d0 + 2 * h < D) ? z[i * D + d0 + 2 * h] : 0.f;
+        zr[h].y = (d0 + 2 * h + 1 < D) ? z[i * D + d0 + 2 * h + 1] : 0.f;
+        s2[h] = (f32x2){0.f, 0.f};
+    }
+    // posterior parameters travel through scalar registers (wave-uniform loads)
+    const float* __restrict__ pj = dparams + j0 * 3 * DC + d0;
+    for (int64_t j = j0; j < j1; ++j, pj += 3 * DC) {
+        const f32x2* __restrict__ pm = reinterpret_cast<const f32x2*>(pj);
+        const f32x2* __restrict__ pw = reinterpret_cast<const f32x2*>(pj + DC);
+        const f32x2* __restrict__ pb = reinterpret_cast<const f32x2*>(pj + 2 * DC);
+        // four independent pairs per stage, so that no instruction waits on the one before it
+#pragma unroll
+        for (int hb = 0; hb < DCT / 2; hb += 4) {
+            f32x2 y[4], e[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = zr[hb + k] - pm[hb + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] *= pw[hb + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = __builtin_elementwise_fma(-y[k], y[k], pb[hb + k]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                e[k].x = lvae_exp2(y[k].x);
+                e[k].y = lvae_exp2(y[k].y);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s2[hb + k] += e[k];
+            __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    bool ok = true;
+#pragma unroll
+    for (int h = 0; h < DCT / 2; ++h)
+        ok = ok && s2[h].x >= PM_SUM_MIN && s2[h].x <= PM_SUM_MAX && s2[h].y >= PM_SUM_MIN &&
+             s2[h].y <= PM_SUM_MAX;
+    const bool redo = !__all(ok);
+    if ((threadIdx.x & 63) == 0)
+        redo_flags[((int64_t)blockIdx.y * (DC / 16) + d0 / 16) * (cpad / 64) + col / 64] = redo ? 1 : 0;
+    if (redo || col >= C) return;
+    float2* __restrict__ o = partial_pm + ((int64_t)blockIdx.y * DC + d0) * cpad + col;
+#pragma unroll
+    for (int h = 0; h < DCT / 2; ++h) {
+        o[(int64_t)(2 * h) * cpad] = make_float2(0.f, s2[h].x);
+        o[(int64_t)(2 * h + 1) * cpad] = make_float2(0.f, s2[h].y);
+    }
+}
+
+// Running-maximum sweep (lazy: the reference only moves when a term exceeds it by 2^DLSE_THR) for the
+// waves flagged by pair_pm_kernel; 16 dimensions per workgroup (blockIdx.z), flags indexed by the
+// 16-dimension group the fast kernel's launch at dimension offset `d0 = 16 * (blockIdx.z / zper * zper)`
+// covered.
+__global__ void __launch_bounds__(256)
+pair_pm_online_kernel(const float* __restrict__ z, const float* __restrict__ dparams,
+                      float2* __restrict__ partial_pm, const int* __restrict__ redo_flags, int64_t C,
+                      int64_t cpad, int64_t R, int64_t rows_per_split, int D, int DC, int zper) {
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int fgroup = (int)(blockIdx.z / zper) * zper;   // first 16-dim group of the fast launch
+    if (redo_flags[((int64_t)blockIdx.y * (DC / 16) + fgroup) * (cpad / 64) + col / 64] == 0) return;
+    const int64_t i = col < C ? col : C - 1;
+    const int g0 = 16 * (int)blockIdx.z;
+    const int64_t j0 = (int64_t)blockIdx.y * rows_per_split;
+    int64_t j1 = j0 + rows_per_split;
+    if (j1 > R) j1 = R;
+    float zr[16], m[16], s[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        zr[e] = (g0 + e < D) ? z[i * D + g0 + e] : 0.f;
+        m[e] = DLSE_MINIT;
+        s[e] = 0.f;
+    }
+    for (int64_t j = j0; j < j1; ++j) {
+        const float* __restrict__ pm = dparams + (j * 3 + 0) * DC + g0;
+        const float* __restrict__ pw = dparams + (j * 3 + 1) * DC + g0;
+        const float* __restrict__ pb = dparams + (j * 3 + 2) * DC + g0;
+        float t16[16];
+        float ex = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float y = (zr[e] - pm[e]) * pw[e];
+            t16[e] = fmaf(-y, y, pb[e]);
+            ex = fmaxf(ex, t16[e] - m[e]);
+        }
+        if (__any(ex > DLSE_THR)) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float x = t16[e] - m[e];
+                if (x > DLSE_THR) {
+                    s[e] = s[e] * lvae_exp2(-x) + 1.0f;
+                    m[e] = t16[e];
+                } else {
+                    s[e] += lvae_exp2(x);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] += lvae_exp2(t16[e] - m[e]);
+        }
+    }
+    if (col < C) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            partial_pm[((int64_t)blockIdx.y * DC + g0 + e) * cpad + col] = make_float2(m[e], s[e]);
     }
 }
 
@@ -155,53 +232,67 @@ pair_direct_generic_kernel(const float* __restrict__ z, const float* __restrict_
 }
 
 template <int DCT>
-static int launch_chunk(const PairPlan& p, bool joint, bool pm, const float* z, const float* dparams,
-                        float2* partial, float2* partial_pm, const PairHeader* hdr, float cond_limit,
-                        int use_if_above, int d0, int excl, int64_t excl_offset, hipStream_t st) {
+static int launch_joint(const PairPlan& p, const float* z, const float* dparams, float2* partial,
+                        const PairHeader* hdr, float cond_limit, int use_if_above, int excl,
+                        int64_t excl_offset, hipStream_t st) {
     const dim3 grid((unsigned)(p.cpad / 256), (unsigned)p.dsplit);
-#define LVAE_DIRECT(J, P)                                                                         \
-    hipLaunchKernelGGL((pair_direct_kernel<DCT, J, P>), grid, dim3(256), 0, st, z, dparams, partial, \
-                       partial_pm, hdr, cond_limit, use_if_above, p.C, p.cpad, p.R,                \
-                       p.rows_per_dsplit, p.D, p.DC, d0, excl, excl_offset)
-    if (joint && pm) LVAE_DIRECT(true, true);
-    else if (joint) LVAE_DIRECT(true, false);
-    else LVAE_DIRECT(false, true);
-#undef LVAE_DIRECT
+    hipLaunchKernelGGL((pair_direct_kernel<DCT>), grid, dim3(256), 0, st, z, dparams, partial, hdr,
+                       cond_limit, use_if_above, p.C, p.cpad, p.R, p.rows_per_dsplit, p.D, p.DC, excl,
+                       excl_offset);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }
 
-// joint: produce the log q(z) partials; pm: produce the product-of-marginals partials.
+template <int DCT>
+static int launch_pm(const PairPlan& p, const float* z, const float* dparams, float2* partial_pm,
+                     int* redo_flags, int d0, hipStream_t st) {
+    const dim3 grid((unsigned)(p.cpad / 256), (unsigned)p.dsplit);
+    hipLaunchKernelGGL((pair_pm_kernel<DCT>), grid, dim3(256), 0, st, z, dparams, partial_pm, redo_flags,
+                       p.C, p.cpad, p.R, p.rows_per_dsplit, p.D, p.DC, d0);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+// joint: produce the log q(z) partials (gated on the conditioning estimate when cond_limit >= 0);
+// pm: produce the product-of-marginals partials (never gated).
 // The direct parameters are padded (w = b = 0, a zero term) to DC columns: 16/32/64 for D <= 64, where
-// one fused kernel keeps the whole latent row in registers, else a multiple of 16.
+// the kernels keep the whole latent row in registers, else a multiple of 16.
 int lvae_launch_pair_direct(const PairPlan& p, bool joint, bool pm, const float* z,
-                            const float* dparams, float2* partial, float2* partial_pm,
+                            const float* dparams, float2* partial, float2* partial_pm, int* redo_flags,
                             const PairHeader* hdr, float cond_limit, int use_if_above, int excl,
                             int64_t excl_offset, hipStream_t st) {
     if (p.cpad % 256 != 0)
         return lvae_set_error(LVAE_ERR_INVALID, "pair plan: cpad %lld not a multiple of 256",
                               (long long)p.cpad);
     const int DC = p.DC;
-    if (DC == 16 || DC == 32 || DC == 64) {
-        // whole latent row in registers: joint and pm fused in one sweep
-        if (DC == 16) return launch_chunk<16>(p, joint, pm, z, dparams, partial, partial_pm, hdr, cond_limit, use_if_above, 0, excl, excl_offset, st);
-        if (DC == 32) return launch_chunk<32>(p, joint, pm, z, dparams, partial, partial_pm, hdr, cond_limit, use_if_above, 0, excl, excl_offset, st);
-        return launch_chunk<64>(p, joint, pm, z, dparams, partial, partial_pm, hdr, cond_limit, use_if_above, 0, excl, excl_offset, st);
-    }
+    int rc = LVAE_OK;
     if (joint) {
-        const dim3 grid((unsigned)(p.cpad / 256), (unsigned)p.dsplit);
-        hipLaunchKernelGGL(pair_direct_generic_kernel, grid, dim3(256), 0, st, z, dparams, partial,
-                           hdr, cond_limit, use_if_above, p.C, p.cpad, p.R, p.rows_per_dsplit, p.D,
-                           DC, excl, excl_offset);
-        LVAE_LAUNCH_CHECK();
+        if (DC == 16) rc = launch_joint<16>(p, z, dparams, partial, hdr, cond_limit, use_if_above, excl, excl_offset, st);
+        else if (DC == 32) rc = launch_joint<32>(p, z, dparams, partial, hdr, cond_limit, use_if_above, excl, excl_offset, st);
+        else if (DC == 64) rc = launch_joint<64>(p, z, dparams, partial, hdr, cond_limit, use_if_above, excl, excl_offset, st);
+        else {
+            const dim3 grid((unsigned)(p.cpad / 256), (unsigned)p.dsplit);
+            hipLaunchKernelGGL(pair_direct_generic_kernel, grid, dim3(256), 0, st, z, dparams, partial,
+                               hdr, cond_limit, use_if_above, p.C, p.cpad, p.R, p.rows_per_dsplit, p.D,
+                               DC, excl, excl_offset);
+            LVAE_LAUNCH_CHECK();
+        }
+        if (rc != LVAE_OK) return rc;
     }
     if (pm) {
-        // per-dimension states are independent: sweep the latent row in 16-wide chunks (DC % 16 == 0)
-        for (int d0 = 0; d0 < DC; d0 += 16) {
-            int rc = launch_chunk<16>(p, false, true, z, dparams, nullptr, partial_pm, hdr, -1.f, 0,
-                                      d0, 0, 0, st);
+        // per-dimension states are independent: latent rows wider than 32 are swept in 32-wide chunks
+        int zper = DC >= 32 ? 2 : 1;
+        for (int d0 = 0; d0 < DC; d0 += 32) {
+            if (DC - d0 >= 32) rc = launch_pm<32>(p, z, dparams, partial_pm, redo_flags, d0, st);
+            else rc = launch_pm<16>(p, z, dparams, partial_pm, redo_flags, d0, st);
             if (rc != LVAE_OK) return rc;
         }
+        // DC % 32 == 16: the last fast launch covers one group, and its flag sits at that group's index,
+        // which (blockIdx.z / 2) * 2 also yields because the group index is even
+        const dim3 grid((unsigned)(p.cpad / 256), (unsigned)p.dsplit, (unsigned)(DC / 16));
+        hipLaunchKernelGGL(pair_pm_online_kernel, grid, dim3(256), 0, st, z, dparams, partial_pm,
+                           redo_flags, p.C, p.cpad, p.R, p.rows_per_dsplit, p.D, DC, zper);
+        LVAE_LAUNCH_CHECK();
     }
     return LVAE_OK;
 }

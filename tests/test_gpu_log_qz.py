@@ -72,6 +72,36 @@ def test_log_qz_vs_oracle(N, M, D):
         assert rel(lqpm.double().mean(), refpm.mean()) < 1e-4, path
 
 
+def test_prod_marginals_redo_path():
+    """Samples ~50 sigma away from every posterior underflow the fixed-reference fast pass of the
+    prod-marginals kernel; the flagged waves must be redone with the running-maximum form, and the
+    other waves of the same call must keep their fast-pass results."""
+    from lvae import estimators as E
+    rng = np.random.default_rng(7)
+    N, M, D = 700, 1000, 32
+    mu = rng.standard_normal((N, D)).astype(np.float32)
+    logvar = (0.3 * rng.standard_normal((N, D)) - 2.0).astype(np.float32)
+    z = rng.standard_normal((M, D)).astype(np.float32)
+    z[100:180] += 40.0                      # far in every dimension
+    z[500:520, 3] -= 25.0                   # far in one dimension only
+    z[900:, :] *= 1e3                       # absurdly far: densities far below fp32 range in linear space
+    ref, refpm = onp.approximate_log_q_z(mu, logvar, z, method="all", prod_marginals=True, reduce_mean=False)
+    for path in ("auto", "direct"):
+        lq, lqpm = E.approximate_log_q_z(dev(mu), dev(logvar), dev(z), method="all", prod_marginals=True,
+                                         reduce_mean=False, path=PATHS[path])
+        np.testing.assert_allclose(lqpm.cpu().numpy(), refpm, rtol=1e-4, err_msg=path)
+        np.testing.assert_allclose(lq.cpu().numpy(), ref, rtol=1e-4, atol=1e-3, err_msg=path)
+    # tiny and huge variances: b_jd outside the fast pass's range in both directions
+    logvar2 = logvar.copy()
+    logvar2[:, 0] = -60.0
+    logvar2[:, 1] = 100.0
+    _, refpm2 = onp.approximate_log_q_z(mu, logvar2, z[:64], method="all", prod_marginals=True,
+                                        reduce_mean=False)
+    _, lqpm2 = E.approximate_log_q_z(dev(mu), dev(logvar2), dev(z[:64]), method="all", prod_marginals=True,
+                                     reduce_mean=False, path=PATHS["direct"])
+    np.testing.assert_allclose(lqpm2.cpu().numpy(), refpm2, rtol=1e-4)
+
+
 def test_q1_raises():
     from lvae import estimators as E
     g = load_golden("logqz_generic")
