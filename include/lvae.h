@@ -167,6 +167,16 @@ int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int64_t n2, int
                      int n_alpha, float dist_eps, int unbiased, double* out, void* ws, int64_t ws_bytes,
                      void* stream);
 
+/* One block of the kernel-matrix sums above: sum over i < na, j < nb of k(a_i, b_j), same kernel k as
+ * lvae_mmd_rbf_f32, optionally skipping the pairs j == i + diag_offset (exclude_diag != 0).  This is the
+ * multi-GPU building block of the MMD (a = this rank's rows, b = the gathered sample, diag_offset = the
+ * rank's first row; loss_and_optimisation.py:46-60,:617-619 evaluate the whole matrix in one process).
+ * out_total: 1 float64 (may be NULL); out_colsum: [na] float64, the per-a_i sums over j (may be NULL). */
+int lvae_kernel_sum_workspace_bytes(int64_t na, int64_t nb, int D, int64_t* out_bytes);
+int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, int64_t nb, int D, const float* alphas,
+                        int n_alpha, float dist_eps, int exclude_diag, int64_t diag_offset,
+                        double* out_total, double* out_colsum, void* ws, int64_t ws_bytes, void* stream);
+
 /* The kernel matrix itself (gaussian_kernel, loss_and_optimisation.py:63-76; MMDStatistic ret_matrix):
  * out[i, j] = k(x_i, y_j), out [n1, n2]; alphas on the HOST as above.  Workspace: LVAE_KMAT_WS_BYTES. */
 #define LVAE_KMAT_WS_BYTES 4096

@@ -58,6 +58,9 @@ int lvae_launch_diag_ll(const float* z, const float* mu, const float* spread, in
 int lvae_launch_bounds_finalize(const float* diag, const float* lse_all, const float* lse_off, int64_t n,
                                 double* out, hipStream_t st);
 int lvae_launch_set_ksum(PairHeader* hdr, const KsumParams& kp, hipStream_t st);
+int lvae_launch_ksum_columns(const double* partial, int nsplit, int64_t cpad, int64_t C, int64_t R, int excl,
+                             int64_t excl_offset, int zero_alphas, double* colsum, double* total,
+                             hipStream_t st);
 int lvae_launch_mmd_stat(const double* sums, int64_t n1, int64_t n2, int unbiased, int zero_alphas,
                          double* out, hipStream_t st);
 
@@ -558,6 +561,55 @@ extern "C" int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int6
         if (rc) return rc;
     }
     return lvae_launch_mmd_stat(sums, n1, n2, unbiased, zeros, out, st);
+}
+
+extern "C" int lvae_kernel_sum_workspace_bytes(int64_t na, int64_t nb, int D, int64_t* out_bytes) {
+    LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
+    LVAE_CHECK_ARG(na >= 1 && nb >= 1 && D >= 1, "need na, nb, D >= 1");
+    const PairPlan p = lvae_make_pair_plan(nb, na, D, false);
+    *out_bytes = (int64_t)p.total;
+    return LVAE_OK;
+}
+
+extern "C" int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, int64_t nb, int D,
+                                   const float* alphas, int n_alpha, float dist_eps, int exclude_diag,
+                                   int64_t diag_offset, double* out_total, double* out_colsum, void* ws,
+                                   int64_t ws_bytes, void* stream) {
+    LVAE_CHECK_ARG(a && b, "a and b must be non-NULL");
+    LVAE_CHECK_ARG(out_total || out_colsum, "at least one of out_total / out_colsum is required");
+    LVAE_CHECK_ARG(na >= 1 && nb >= 1, "need na, nb >= 1");
+    LVAE_CHECK_ARG(D >= 1 && D <= 128, "the kernel-sum path needs 1 <= D <= 128 (got %d)", D);
+    LVAE_CHECK_ARG(na < (1LL << 31) && nb < (1LL << 31), "na, nb must be below 2^31");
+    KsumParams kp;
+    int zeros = 0;
+    int rc = build_ksum(alphas, n_alpha, dist_eps, &kp, &zeros);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const PairPlan p = lvae_make_pair_plan(nb, na, D, false);
+    rc = check_ws(ws, ws_bytes, p.total);
+    if (rc) return rc;
+    char* base = (char*)ws;
+    PairHeader* hdr = (PairHeader*)(base + p.off_hdr);
+    float2* partial = (float2*)(base + p.off_partial);
+    LVAE_HIP(hipMemsetAsync(hdr, 0, sizeof(PairHeader), st));   // colsum = 0 -> no centering shift
+    rc = lvae_launch_set_ksum(hdr, kp, st);
+    if (rc) return rc;
+    if (kp.n == 0 && kp.c[0] == 0.f) {      // only alpha = 0 bandwidths: no pair kernel needed
+        LVAE_HIP(hipMemsetAsync(partial, 0, (size_t)p.nsplit * p.cpad * sizeof(double), st));
+    } else {
+        rc = lvae_launch_prep(2, true, b, nullptr, 0, nb, p.nblk * 32, D, p.DP, hdr, 1,
+                              (float*)(base + p.off_rfrag), (float*)(base + p.off_rbias), nullptr, p.DC, st);
+        if (rc) return rc;
+        rc = lvae_launch_prep(1, false, a, nullptr, 0, na, p.cpad, D, p.DP, hdr, 1, (float*)(base + p.off_cop),
+                              nullptr, nullptr, p.DC, st);
+        if (rc) return rc;
+        rc = lvae_launch_pair_mfma(p, (float*)(base + p.off_rfrag), (float*)(base + p.off_rbias),
+                                   (float*)(base + p.off_cop), partial, hdr, -1.f, 0, exclude_diag != 0,
+                                   diag_offset, ksum_epi(kp), st);
+        if (rc) return rc;
+    }
+    return lvae_launch_ksum_columns((const double*)partial, p.nsplit, p.cpad, na, nb, exclude_diag != 0,
+                                    diag_offset, zeros, out_colsum, out_total, st);
 }
 
 extern "C" int lvae_kernel_matrix_f32(const float* x, const float* y, int64_t n1, int64_t n2, int D,

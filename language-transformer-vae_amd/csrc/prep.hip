@@ -298,3 +298,35 @@ int lvae_launch_finalize_ksum(const double* partial, int nsplit, int64_t cpad, i
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }
+
+// Per-kept-element kernel sums from the float64 partials [nsplit][cpad], plus the alpha = 0 bandwidths'
+// constant (+1 per counted pair): colsum[i] = sum_k partial[k][i] + zero_alphas * (#pairs counted for i).
+__global__ void __launch_bounds__(256) ksum_columns_kernel(const double* __restrict__ partial, int nsplit,
+                                                           int64_t cpad, int64_t C, int64_t R, int excl,
+                                                           int64_t excl_offset, double zero_alphas,
+                                                           double* __restrict__ colsum, double* __restrict__ total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double acc = 0.0;
+    if (i < C) {
+        for (int k = 0; k < nsplit; ++k) acc += partial[k * cpad + i];
+        const int64_t js = i + excl_offset;
+        const int64_t pairs = R - ((excl && js >= 0 && js < R) ? 1 : 0);
+        acc += zero_alphas * (double)pairs;
+        if (colsum) colsum[i] = acc;
+    }
+    acc = wave_sum_d(acc);
+    __shared__ double sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && total) atomicAdd(total, sm[0] + sm[1] + sm[2] + sm[3]);
+}
+
+int lvae_launch_ksum_columns(const double* partial, int nsplit, int64_t cpad, int64_t C, int64_t R, int excl,
+                             int64_t excl_offset, int zero_alphas, double* colsum, double* total,
+                             hipStream_t st) {
+    if (total) LVAE_HIP(hipMemsetAsync(total, 0, sizeof(double), st));
+    hipLaunchKernelGGL(ksum_columns_kernel, dim3((unsigned)lvae_ceil_div(C, 256)), dim3(256), 0, st, partial,
+                       nsplit, cpad, C, R, excl, excl_offset, (double)zero_alphas, colsum, total);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}

@@ -145,6 +145,37 @@ def sharded_iw_log_p_x(mu_local, logvar_local, eps_local, log_p_x_z_local, group
     return out.reshape(-1)
 
 
+def hip_kernel_sum(a, b, alphas, dist_eps, exclude_diag, diag_offset):
+    """Per-rank compute of sharded_mmd on the HIP path: float64 device scalar."""
+    from . import estimators as E
+    return E.kernel_sum(a, b, alphas, dist_eps, exclude_diag, diag_offset)
+
+
+def sharded_mmd(x_local, y_local, alphas, dist_eps=0.0, unbiased=False, group=None,
+                kernel_sum=hip_kernel_sum):
+    """Gaussian-kernel MMD between two samples whose rows are sharded over ranks (the samples
+    are replicated by all-gather, the kernel-matrix rows are partitioned, three float64 block sums are
+    all-reduced).  ``unbiased=True``, ``dist_eps=1e-5`` is the torch-two-sample statistic used at
+    loss_and_optimisation.py:617-619 (diagonals excluded, 1/(n(n-1)) weights); ``unbiased=False``,
+    ``dist_eps=0``, ``alphas=[1/D^2]`` is maximum_mean_discrepancy (:46-60).  Returns a dict of Python
+    floats, identical on every rank."""
+    x_all, xoff = all_gather_rows(x_local.contiguous(), group)
+    y_all, yoff = all_gather_rows(y_local.contiguous(), group)
+    rank = dist.get_rank(group)
+    sums = torch.stack([
+        kernel_sum(x_local, x_all, alphas, dist_eps, unbiased, xoff[rank]).reshape(()),
+        kernel_sum(y_local, y_all, alphas, dist_eps, unbiased, yoff[rank]).reshape(()),
+        kernel_sum(x_local, y_all, alphas, dist_eps, False, 0).reshape(()),
+    ]).to(torch.float64)
+    _all_reduce(sums, dist.ReduceOp.SUM, group)
+    sxx, syy, sxy = sums.tolist()
+    n1, n2 = float(x_all.shape[0]), float(y_all.shape[0])
+    c11 = n1 * (n1 - 1.0) if unbiased else n1 * n1
+    c22 = n2 * (n2 - 1.0) if unbiased else n2 * n2
+    return {"mmd": sxx / c11 + syy / c22 - 2.0 * sxy / (n1 * n2), "sum_kxx": sxx, "sum_kyy": syy,
+            "sum_kxy": sxy, "n1": int(n1), "n2": int(n2)}
+
+
 def combine_partial_lse(row_max, row_sum, log_norm, group=None):
     """Column-sharded alternative: every rank holds ALL z rows but only its posteriors and has produced
     (row_max, row_sum) with lvae_log_qz_partial_f32.  all-reduce(max), rescale, all-reduce(sum)."""

@@ -101,3 +101,61 @@ def test_sharded_latent_stats_world2(ragged):
         np.testing.assert_allclose(comb, lq_all, rtol=1e-5, atol=1e-4)     # float32 partials
         np.testing.assert_allclose(lq_local, lq[lo:hi], rtol=1e-12, atol=1e-9)
     assert results[0][1] == results[1][1]      # identical on every rank
+
+
+def _oracle_kernel_sum(a, b, alphas, dist_eps, exclude_diag, diag_offset):
+    a64, b64 = a.numpy().astype(np.float64), b.numpy().astype(np.float64)
+    d2 = dist_eps + np.abs((a64 ** 2).sum(1)[:, None] + (b64 ** 2).sum(1)[None] - 2.0 * a64 @ b64.T)
+    K = sum(np.exp(-al * d2) for al in alphas)
+    if exclude_diag:
+        i = np.arange(a64.shape[0])
+        j = i + diag_offset
+        ok = (j >= 0) & (j < b64.shape[0])
+        K[i[ok], j[ok]] = 0.0
+    return torch.tensor(K.sum(), dtype=torch.float64)
+
+
+def _mmd_worker(rank, world, port, n1, n2, D, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lvae import distributed as LD
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((n1, D)).astype(np.float32)
+    y = (0.8 * rng.standard_normal((n2, D)) + 0.1).astype(np.float32)
+    xs = x[:n1 // 3] if rank == 0 else x[n1 // 3:]          # ragged shards
+    ylo, yhi = LD.shard_bounds(n2, world, rank)
+    alphas = [0.1 * i for i in range(15)]
+    tts = LD.sharded_mmd(torch.from_numpy(xs.copy()), torch.from_numpy(y[ylo:yhi].copy()), alphas, 1e-5, True,
+                         kernel_sum=_oracle_kernel_sum)
+    biased = LD.sharded_mmd(torch.from_numpy(xs.copy()), torch.from_numpy(y[ylo:yhi].copy()), [1.0 / D ** 2], 0.0,
+                            False, kernel_sum=_oracle_kernel_sum)
+    q.put((rank, tts, biased))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_mmd_world2():
+    from oracle import oracle_np as onp
+    n1, n2, D, world = 70, 53, 8, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mmd_worker, args=(r, world, port, n1, n2, D, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((n1, D)).astype(np.float32)
+    y = (0.8 * rng.standard_normal((n2, D)) + 0.1).astype(np.float32)
+    want_tts = onp.mmd_statistic_tts(x, y, [0.1 * i for i in range(15)])
+    want_biased = onp.maximum_mean_discrepancy(y, x)
+    for rank, tts, biased in results:
+        assert abs(tts["mmd"] - want_tts) <= 1e-9 * max(1.0, abs(want_tts)), (tts, want_tts)
+        assert abs(biased["mmd"] - want_biased) <= 1e-9 * max(1.0, abs(want_biased)), (biased, want_biased)
+        assert tts["n1"] == n1 and tts["n2"] == n2
+    assert results[0][1] == results[1][1]

@@ -156,6 +156,36 @@ def test_tts_mmd_unpinned(n1, n2, D):
     assert abs(got3 - ref3) <= 2e-6 * 15
 
 
+@pytest.mark.parametrize("na,nb,D,off", [(300, 500, 32, 120), (257, 257, 64, 0), (90, 700, 16, -10),
+                                         (130, 64, 128, 40)])
+def test_kernel_sum_blocks(na, nb, D, off):
+    """Row-block kernel sums (the multi-GPU MMD building block) against float64 NumPy, with the
+    excluded diagonal at an offset, alpha = 0 bandwidths, and per-row sums."""
+    from lvae import estimators as E
+    rng = np.random.default_rng(na + nb)
+    a = rng.standard_normal((na, D)).astype(np.float32)
+    b = (0.9 * rng.standard_normal((nb, D)) + 0.2).astype(np.float32)
+    if off >= 0 and na + off <= nb:
+        b[off:off + na] = a                 # the excluded pairs are genuine self-pairs
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    for alphas, eps in (([0.1 * i for i in range(15)], 1e-5), ([1.0 / D ** 2], 0.0), ([0.0, 0.07, 0.19], 1e-5),
+                        ([0.0, 0.0], 0.0)):
+        d2 = eps + np.abs((a64 ** 2).sum(1)[:, None] + (b64 ** 2).sum(1)[None] - 2.0 * a64 @ b64.T)
+        K = sum(np.exp(-al * d2) for al in alphas)
+        for excl in (False, True):
+            Kx = K.copy()
+            if excl:
+                i = np.arange(na)
+                j = i + off
+                ok = (j >= 0) & (j < nb)
+                Kx[i[ok], j[ok]] = 0.0
+            tot, cs = E.kernel_sum(dev(a), dev(b), alphas, eps, excl, off, colsum=True)
+            assert abs(float(tot) - Kx.sum()) <= 2e-6 * Kx.sum(), (alphas, excl)
+            np.testing.assert_allclose(cs.cpu().numpy(), Kx.sum(1), rtol=1e-5)
+            tot2 = E.kernel_sum(dev(a), dev(b), alphas, eps, excl, off)
+            assert float(tot2) == float(tot)
+
+
 def test_get_tts_mmmd_and_encode_tail():
     from lvae import encoder_ops as EO
     from lvae import estimators as E
