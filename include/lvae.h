@@ -177,6 +177,25 @@ int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, int64_t nb, 
                         int n_alpha, float dist_eps, int exclude_diag, int64_t diag_offset,
                         double* out_total, double* out_colsum, void* ws, int64_t ws_bytes, void* stream);
 
+/* Label-permutation sums for the MMD permutation test (torch_two_sample MMDStatistic.pval; the C4
+ * benchmark configuration; never called by the reference itself -- PARITY UNPINNED like the statistic).
+ * pooled [n,D]: both samples stacked; cols [nc,D]: the rows col_offset .. col_offset+nc-1 of it that this
+ * call (this rank) owns; labels [P][n] uint8 in device memory, labels[p][i] != 0 <=> under labeling p element
+ * i belongs to sample 1 (P <= 128 per call).  With K the pooled kernel matrix of lvae_mmd_rbf_f32 (alpha > 0
+ * bandwidths only -- alpha = 0 adds exactly 0 to the statistic -- diagonal excluded), L_p the indicator
+ * vector of labeling p and r = K 1, out receives 2P+1 float64:
+ *     out[p]      = sum over owned columns c of L_p[c] * (K L_p)[c]      (q_p; all columns: L_p^T K L_p)
+ *     out[P + p]  = sum over owned columns c of L_p[c] * r[c]
+ *     out[2P]     = sum over owned columns of r[c]                       (T)
+ * Summed over all owners: k11 = q_p, k12 = lr_p - q_p, k22 = T - 2 lr_p + q_p and
+ * statistic_p = k11/(n1(n1-1)) + k22/(n2(n2-1)) - 2 k12/(n1 n2).  The kernel values enter the label
+ * contraction as two bf16 limbs (relative error <= 2^-17 per entry, unbiased); bandwidths must be integer
+ * multiples (<= 16) of the smallest positive one. */
+int lvae_mmd_perm_workspace_bytes(int64_t nc, int64_t n, int D, int64_t* out_bytes);
+int lvae_mmd_perm_f32(const float* cols, int64_t nc, int64_t col_offset, const float* pooled, int64_t n, int D,
+                      const unsigned char* labels, int P, const float* alphas, int n_alpha, float dist_eps,
+                      double* out, void* ws, int64_t ws_bytes, void* stream);
+
 /* The kernel matrix itself (gaussian_kernel, loss_and_optimisation.py:63-76; MMDStatistic ret_matrix):
  * out[i, j] = k(x_i, y_j), out [n1, n2]; alphas on the HOST as above.  Workspace: LVAE_KMAT_WS_BYTES. */
 #define LVAE_KMAT_WS_BYTES 4096

@@ -248,3 +248,81 @@ int lvae_launch_mmd_stat(const double* sums, int64_t n1, int64_t n2, int unbiase
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }
+
+// ---- MMD permutation test -----------------------------------------------------------------------------
+// 0/1 labels [P][n] (one row per labeling) -> bf16 fragments in the order the PERM mode of the MFMA pair
+// kernel consumes them as B operands of v_mfma_f32_32x32x16_bf16: per 32-row block
+// [4 labeling tiles][2 steps][64 lanes][8 values]; lane = labeling (low 5 bits) + 32 * k-half; value e of
+// step s belongs to the row the accumulator layout puts in register 8 s + e of that half:
+// (reg & 3) + 8 (reg >> 2) + 4 half.
+__global__ void __launch_bounds__(256) prep_labels_kernel(const unsigned char* __restrict__ labels, int P,
+                                                          int64_t n, int64_t nblk, uint4* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nblk * 512) return;
+    const int lane = (int)(idx & 63);
+    const int sp = (int)((idx >> 6) & 1);
+    const int pt = (int)((idx >> 7) & 3);
+    const int64_t blk = idx >> 9;
+    const int perm = 32 * pt + (lane & 31);
+    const int kh = lane >> 5;
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    if (perm < P) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int reg = 8 * sp + e;
+            const int64_t row = blk * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+            if (row < n && labels[(int64_t)perm * n + row]) w[e >> 1] |= 0x3F80u << (16 * (e & 1));   // bf16 1.0
+        }
+    }
+    out[idx] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Block p < P: lr_p = sum_i label[p][col_offset + i] * r_i with r_i = sum_k partial[k][i] (the kernel
+// sums of kept element i over the whole pooled sample); block P: T = sum_i r_i.
+// out = [q_0..q_{P-1}, lr_0..lr_{P-1}, T].
+__global__ void __launch_bounds__(256) perm_lr_kernel(const double* __restrict__ partial, int nsplit,
+                                                      int64_t cpad, int64_t C,
+                                                      const unsigned char* __restrict__ labels, int64_t n,
+                                                      int64_t col_offset, int P,
+                                                      const double* __restrict__ qperm,
+                                                      double* __restrict__ out) {
+    const int p = blockIdx.x;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < C; i += 256) {
+        if (p == P || labels[(int64_t)p * n + col_offset + i]) {
+            double r = 0.0;
+            for (int k = 0; k < nsplit; ++k) r += partial[k * cpad + i];
+            acc += r;
+        }
+    }
+    acc = wave_sum_d(acc);
+    __shared__ double sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = sm[0] + sm[1] + sm[2] + sm[3];
+        if (p == P) out[2 * P] = tot;
+        else {
+            out[P + p] = tot;
+            out[p] = qperm[p];
+        }
+    }
+}
+
+int lvae_launch_prep_labels(const unsigned char* labels, int P, int64_t n, int64_t nblk, void* out,
+                            hipStream_t st) {
+    const int64_t total = nblk * 512;
+    hipLaunchKernelGGL(prep_labels_kernel, dim3((unsigned)lvae_ceil_div(total, 256)), dim3(256), 0, st, labels,
+                       P, n, nblk, (uint4*)out);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+int lvae_launch_perm_lr(const double* partial, int nsplit, int64_t cpad, int64_t C,
+                        const unsigned char* labels, int64_t n, int64_t col_offset, int P,
+                        const double* qperm, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(perm_lr_kernel, dim3((unsigned)(P + 1)), dim3(256), 0, st, partial, nsplit, cpad, C,
+                       labels, n, col_offset, P, qperm, out);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}

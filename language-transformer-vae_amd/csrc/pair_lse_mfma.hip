@@ -6,10 +6,9 @@
 // come from prep.hip.  Each wave owns 32*NCB kept elements for its whole life: their operand rows sit
 // in VGPRs as the B operand of v_mfma_f32_32x32x2_f32 (lane = column + 32*half).  The wave then streams
 // 32-row blocks of the reduced axis through an LDS ring shared by the workgroup's four waves and filled
-// by LDS-DMA (one 1 KiB piece per 4 MFMA steps, fragment-major layout), the accumulators start from the row bias, DP chained MFMAs per
-// 32x32 tile
-// produce the base-2 log-densities, and the epilogue folds the 16 values a lane holds (16 reduced rows
-// of its own column) into that lane's running (max, sum).  The reduction axis lives on the MFMA ROW
+// by LDS-DMA (one 1 KiB piece per 4 MFMA steps, fragment-major layout), the accumulators start from the
+// row bias, DP chained MFMAs per 32x32 tile produce the base-2 log-densities, and the epilogue folds the
+// 16 values a lane holds (16 reduced rows of its own column) into that lane's running (max, sum).  The reduction axis lives on the MFMA ROW
 // index, i.e. in registers, so the logsumexp needs no cross-lane traffic until the very end, where
 // the two half-waves (rows +0..3 / +4..7 of every 8) are merged with one wave shuffle.
 //
@@ -47,12 +46,23 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 //        accumulated per column in float64 (one tile's 16 terms are first summed in float32).
 //        poly mode: alpha_k = base * (integer), f is a polynomial in t = exp(-base*v) evaluated by
 //        Horner's rule (one v_exp_f32 per pair for any number of bandwidths).
-template <int DP, int NCB, int WPS, bool EXCL, int EPI>
+// PERM (with EPI 1/2, NCB == 1): label-permutation sums for the MMD permutation test.  Every 32x32
+//        tile of kernel values K[r][c] is, straight from the accumulator layout, the A operand
+//        (i = column c, k = row r) of v_mfma_f32_32x32x16_bf16 against 0/1 label fragments
+//        L[r][p] (128 labelings, four 32-wide tiles), split into two bf16 limbs (hi + lo, ~17 bits):
+//        Y[c][p] += sum_r K[r][c] L[r][p].  Every PERM_FLUSH blocks the lane folds
+//        sum_c L[c][p] Y[c][p] into a float64 and clears Y; at the end q_p = L_p^T K L_p partials go
+//        to `qperm` with float64 atomics.
+#define PERM_FLUSH 16
+
+template <int DP, int NCB, int WPS, bool EXCL, int EPI, bool PERM = false>
 __global__ void __launch_bounds__(256, WPS)
 pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ rbias,
                      const float* __restrict__ cop, float2* __restrict__ partial,
                      const PairHeader* __restrict__ hdr, float cond_limit, int use_if_above,
-                     int64_t nblk, int64_t blk_per_split, int64_t cpad, int64_t excl_offset) {
+                     int64_t nblk, int64_t blk_per_split, int64_t cpad, int64_t excl_offset,
+                     PermArgs pa) {
+    static_assert(!PERM || (NCB == 1 && (EPI == 1 || EPI == 2)), "PERM needs NCB == 1 and a polynomial epilogue");
     // Path gate: the conditioning estimate written by prep decides between this kernel and the direct
     // one without a host round trip (both are launched; the unselected one exits here).
     if (cond_limit >= 0.f) {
@@ -116,6 +126,11 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     constexpr int PF = LVAE_PF;               // chunks the DMA runs ahead of the MFMAs
     constexpr int NST = PF + 1;
     __shared__ __attribute__((aligned(16))) float ring[NST * STAGE_F];
+    // PERM: label fragments of a block are consumed one block after its operand chunks (with the
+    // tile's epilogue), so they live in a ring of their own, deep enough to outlast that delay
+    constexpr int NSTL = 2 + (PF + CPB - 1) / CPB;
+    constexpr int LAB_F = 4 * 2 * 64 * 4;     // floats (= 8 KiB) of label fragments per block
+    __shared__ __attribute__((aligned(16))) float lring[PERM ? NSTL * LAB_F : 4];
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
     typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -128,9 +143,19 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
             const int q = q0 + wave_u;
             __builtin_amdgcn_global_load_lds((gptr_t)(g + q * 256), (lptr_t)(l + q * 256), 16, 0, 0);
         }
-        if (ch == 0)   // 64 lanes x 4 B: this block's 32 biases (+32 of the next block, unused); every wave
+        if (ch == 0) { // 64 lanes x 4 B: this block's 32 biases (+32 of the next block, unused); every wave
                        // writes the same bytes so that all waves have the same DMA count per chunk
             __builtin_amdgcn_global_load_lds((gptr_t)(rbias + blk * 32 + lane), (lptr_t)(l + CHUNK_F), 4, 0, 0);
+            if (PERM) {
+                const float* lg = reinterpret_cast<const float*>(pa.labfrag) + blk * LAB_F + lane * 4;
+                float* ll = lring + (int)((blk - b0) % NSTL) * LAB_F;
+#pragma unroll
+                for (int q0 = 0; q0 < 8; q0 += 4) {
+                    const int q = q0 + wave_u;
+                    __builtin_amdgcn_global_load_lds((gptr_t)(lg + q * 256), (lptr_t)(ll + q * 256), 16, 0, 0);
+                }
+            }
+        }
     };
     // chunk index t (counted from this workgroup's first block) -> (block, chunk-in-block), clamped to
     // the last chunk of the range so that running ahead past the end is a harmless re-read
@@ -164,6 +189,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     // (EPI 1: 17 micro-slices: one pair each, the last one folds the tile sum into float64.)
     constexpr int EPI_MS = EPI >= 1 ? 17 : 10;
     float tmax[NCB];
+    float kv[PERM ? 16 : 1];            // PERM: the kernel values of the tile whose epilogue is running
     // Kernel-sum parameters, read once into (scalar) registers: EPI 1 = one bandwidth (c0 + c1*t),
     // EPI 2 = polynomial of degree <= 16 in t, fully unrolled Horner (unused high coefficients are 0),
     // EPI 3 = arbitrary bandwidths, one exponential each.
@@ -200,7 +226,9 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     auto epi_micro = [&](const f32x16 (&prev)[NCB], int cb, int ms) {
         if (EPI >= 1) {
             if (ms < 16) {
-                kt[cb] += kfun(prev[cb][ms]);
+                const float kval = kfun(prev[cb][ms]);
+                kt[cb] += kval;
+                if (PERM) kv[ms] = kval;
             } else {
                 ks[cb] += (double)kt[cb];
                 kt[cb] = 0.f;
@@ -228,6 +256,72 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
 #endif
         }
     };
+    // ---- PERM: label-permutation accumulators --------------------------------------------------
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    f32x16 Y[PERM ? 4 : 1];
+    double qacc[PERM ? 4 : 1];
+    unsigned cmask[PERM ? 4 : 1];       // bit e: label of kept element (accumulator row e) under labeling 32*pt + r
+    int pcount = 0;
+    if (PERM) {
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            unsigned mk = 0;
+            const int perm = 32 * pt + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t c = col0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (perm < pa.P && c < pa.C && pa.labels[(int64_t)perm * pa.n_lab + pa.col_offset + c]) mk |= 1u << e;
+            }
+            cmask[pt] = mk;
+            qacc[pt] = 0.0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Y[pt][e] = 0.f;
+        }
+    }
+    auto perm_flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int pt = 0; pt < (PERM ? 4 : 0); ++pt) {
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                t += ((cmask[pt] >> e) & 1u) ? Y[pt][e] : 0.f;
+                Y[pt][e] = 0.f;
+            }
+            qacc[pt] += (double)t;
+        }
+    };
+    // kv (the finished tile, accumulator layout: lane = column, 16 rows) -> two bf16 limbs -> 16 MFMAs
+    auto perm_tile = [&](int lstage) __attribute__((always_inline)) {
+        bf16x8 ahi[2], alo[2];
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                const f32x2 v = {kv[8 * sp + 2 * e2], kv[8 * sp + 2 * e2 + 1]};
+                const bf16x2 hh = __builtin_convertvector(v, bf16x2);
+                const f32x2 hf = __builtin_convertvector(hh, f32x2);
+                const bf16x2 ll = __builtin_convertvector(v - hf, bf16x2);
+                ahi[sp][2 * e2] = hh[0];
+                ahi[sp][2 * e2 + 1] = hh[1];
+                alo[sp][2 * e2] = ll[0];
+                alo[sp][2 * e2 + 1] = ll[1];
+            }
+        const bf16x8* lb = reinterpret_cast<const bf16x8*>(lring + lstage * LAB_F);
+#pragma unroll
+        for (int pt = 0; pt < (PERM ? 4 : 0); ++pt)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const bf16x8 b = lb[(pt * 2 + sp) * 64 + lane];
+                Y[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[sp], b, Y[pt], 0, 0, 0);
+                Y[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[sp], b, Y[pt], 0, 0, 0);
+            }
+        if (++pcount == PERM_FLUSH) {
+            perm_flush();
+            pcount = 0;
+        }
+    };
+
     constexpr int SLOTS = DP * NCB;                    // MFMAs per block
     constexpr int MS_TOTAL = EPI_MS * NCB;             // micro-slices per block
 
@@ -291,6 +385,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
                     }
                 }
             }
+            if (PERM && with_epi && ch == CPB - 1) perm_tile((int)((blk - 1 - b0) % NSTL));
             // my pieces of chunk t_lin+2 have landed; after the barrier everybody's have, and
             // everybody is done reading chunk t_lin's stage
             // (chunks t_lin+3 .. t_lin+PF, issued later, may stay in flight: counted wait)
@@ -298,7 +393,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
                 constexpr int per_chunk = CQ / 4;
                 int left = 0;
 #pragma unroll
-                for (int k = 3; k <= PF; ++k) left += per_chunk + (((ch + k) % CPB) == 0 ? 1 : 0);
+                for (int k = 3; k <= PF; ++k) left += per_chunk + (((ch + k) % CPB) == 0 ? (PERM ? 3 : 1) : 0);
                 wait_vmcnt(left);
             }
             __builtin_amdgcn_s_barrier();
@@ -334,6 +429,15 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
         } else {
             drain(accA);
         }
+        if (PERM) {
+            perm_tile((int)((b1 - 1 - b0) % NSTL));
+            if (pcount) perm_flush();
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                const double tot = qacc[pt] + __shfl_xor(qacc[pt], 32, 64);
+                if (h == 0 && 32 * pt + r < pa.P) atomicAdd(&pa.qperm[32 * pt + r], tot);
+            }
+        }
     }
 
     // merge the two half-waves (same column, complementary rows) and publish
@@ -361,10 +465,11 @@ static int launch_t(const PairPlan& p, const float* rfrag, const float* rbias, c
                     float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
                     bool excl, int64_t excl_offset, int epi, hipStream_t st) {
     const dim3 grid((unsigned)(p.cpad / (4 * 32 * NCB)), (unsigned)p.nsplit);
+    const PermArgs pa{};
 #define LVAE_PAIR(X, E)                                                                              \
     hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, NCB, WPS, X, E>), grid, dim3(256), 0, st, rfrag, rbias, \
                        cop, partial, hdr, cond_limit, use_if_above, p.nblk, p.blk_per_split, p.cpad,  \
-                       excl_offset)
+                       excl_offset, pa)
     switch (epi * 2 + (excl ? 1 : 0)) {
         case 0: LVAE_PAIR(false, 0); break;
         case 1: LVAE_PAIR(true, 0); break;
@@ -406,4 +511,41 @@ int lvae_launch_pair_lse_mfma(const PairPlan& p, const float* rfrag, const float
                               hipStream_t st) {
     return lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl,
                                  excl_offset, 0, st);
+}
+
+// Kernel-matrix column sums plus label-permutation sums (see PERM above); diagonal pairs (reduced row ==
+// kept column + excl_offset) are always excluded.  The plan must have NCB == 1; epi 1 or 2.
+template <int DP, int WPS>
+static int launch_perm_t(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
+                         float2* partial, const PairHeader* hdr, int64_t excl_offset, int epi,
+                         const PermArgs& pa, hipStream_t st) {
+    const dim3 grid((unsigned)(p.cpad / (4 * 32)), (unsigned)p.nsplit);
+    if (epi == 1)
+        hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 1, true>), grid, dim3(256), 0, st, rfrag, rbias,
+                           cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa);
+    else
+        hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 2, true>), grid, dim3(256), 0, st, rfrag, rbias,
+                           cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+int lvae_launch_pair_mfma_perm(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
+                               float2* partial, const PairHeader* hdr, int64_t excl_offset, int epi,
+                               const PermArgs& pa, hipStream_t st) {
+    if (p.NCB != 1 || p.cpad % 128 != 0)
+        return lvae_set_error(LVAE_ERR_INVALID, "permutation plan needs NCB == 1 and cpad %% 128 == 0");
+    if (epi != 1 && epi != 2)
+        return lvae_set_error(LVAE_ERR_UNSUPPORTED,
+                              "the permutation test needs bandwidths that are integer multiples (<= 16) of the "
+                              "smallest one");
+    if (pa.P < 1 || pa.P > 128) return lvae_set_error(LVAE_ERR_INVALID, "need 1 <= labelings <= 128 per pass");
+    switch (p.DP) {
+        case 16: return launch_perm_t<16, 2>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, st);
+        case 32: return launch_perm_t<32, 2>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, st);
+        case 64: return launch_perm_t<64, 1>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, st);
+        case 128: return launch_perm_t<128, 1>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, st);
+        default:
+            return lvae_set_error(LVAE_ERR_UNSUPPORTED, "MFMA path needs D <= 128 (got D=%d)", p.D);
+    }
 }

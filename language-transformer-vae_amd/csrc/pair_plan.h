@@ -24,6 +24,17 @@ struct PairHeader {
     unsigned int pad2_[27];
 };
 
+// Arguments of the label-permutation mode of the MFMA pair kernel (MMD permutation test).
+struct PermArgs {
+    const void* labfrag;             // [nblk][4 perm tiles][2 steps][64 lanes][8 bf16] (prep_labels_kernel)
+    const unsigned char* labels;     // [P][n_lab] 0/1, for the kept-axis side
+    double* qperm;                   // [128]
+    int64_t n_lab;                   // pooled sample size (row stride of labels)
+    int64_t col_offset;              // pooled index of kept element 0
+    int64_t C;                       // kept elements
+    int P;
+};
+
 struct PairPlan {
     int64_t R;       // reduced axis length (posteriors for log q(z); samples for q_z_estimate)
     int64_t C;       // kept axis length (one output per element)
@@ -43,11 +54,12 @@ struct PairPlan {
 
 static inline size_t lvae_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool with_pm) {
+static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool with_pm, int force_ncb = 0) {
     PairPlan p{};
     p.R = R; p.C = C; p.D = D; p.with_pm = with_pm;
     p.DP = lvae_pad_dim(D);
     p.NCB = (p.DP == 16 || p.DP == 32) ? 2 : 1;
+    if (force_ncb) p.NCB = force_ncb;
     p.nblk = lvae_ceil_div(R, 32);
     const int64_t wg_cols = p.DP ? 4 * 32 * p.NCB : 256;
     p.cpad = lvae_round_up(C, wg_cols < 256 ? 256 : wg_cols);

@@ -176,6 +176,41 @@ def sharded_mmd(x_local, y_local, alphas, dist_eps=0.0, unbiased=False, group=No
             "sum_kxy": sxy, "n1": int(n1), "n2": int(n2)}
 
 
+def hip_permutation_sums(cols, col_offset, pooled, labels, alphas, dist_eps):
+    from . import estimators as E
+    return E.mmd_permutation_sums(cols, col_offset, pooled, labels, alphas, dist_eps)
+
+
+def sharded_mmd_permutation_test(x_local, y_local, alphas, labels, dist_eps=1e-5, group=None,
+                                 permutation_sums=hip_permutation_sums):
+    """MMD permutation test with both samples sharded by rows (samples replicated by
+    all-gather, kernel-matrix columns partitioned, all-reduce of the [P, 2] label sums and the total).
+    ``labels``: [P, n1 + n2] uint8, identical on every rank (row 0 = observed labeling: first n1 ones), in
+    POOLED order = all of x (rank order) followed by all of y.  Returns a dict identical on every rank."""
+    x_all, xoff = all_gather_rows(x_local.contiguous(), group)
+    y_all, yoff = all_gather_rows(y_local.contiguous(), group)
+    rank = dist.get_rank(group)
+    n1, n2 = x_all.shape[0], y_all.shape[0]
+    pooled = torch.cat((x_all, y_all), 0).contiguous()
+    parts = []
+    for cols, off in ((x_local, xoff[rank]), (y_local, n1 + yoff[rank])):
+        if cols.shape[0] == 0:
+            continue
+        q, lr, tot = permutation_sums(cols.contiguous(), off, pooled, labels, alphas, dist_eps)
+        parts.append(torch.cat((q.reshape(-1), lr.reshape(-1), tot.reshape(1))).to(torch.float64))
+    P = labels.shape[0]
+    sums = torch.stack(parts).sum(0) if parts else torch.zeros(2 * P + 1, dtype=torch.float64,
+                                                               device=pooled.device)
+    _all_reduce(sums, dist.ReduceOp.SUM, group)
+    s = sums.cpu()
+    q, lr, tot = s[:P], s[P:2 * P], s[2 * P]
+    k12 = lr - q
+    k22 = tot - 2.0 * lr + q
+    stats = q / (n1 * (n1 - 1.0)) + k22 / (n2 * (n2 - 1.0)) - 2.0 * k12 / (float(n1) * float(n2))
+    return {"statistic": float(stats[0]), "statistics": stats[1:].tolist(),
+            "pval": float((stats[1:] >= stats[0]).double().mean()) if P > 1 else float("nan")}
+
+
 def combine_partial_lse(row_max, row_sum, log_norm, group=None):
     """Column-sharded alternative: every rank holds ALL z rows but only its posteriors and has produced
     (row_max, row_sum) with lvae_log_qz_partial_f32.  all-reduce(max), rescale, all-reduce(sum)."""

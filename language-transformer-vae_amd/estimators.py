@@ -191,6 +191,77 @@ def kernel_sum(a, b, alphas, dist_eps, exclude_diag=False, diag_offset=0, colsum
     return (total[0], cs) if colsum else total[0]
 
 
+def mmd_permutation_sums(cols, col_offset, pooled, labels, alphas, dist_eps):
+    """Label-permutation sums of the pooled kernel matrix for the columns this caller owns
+    (lvae_mmd_perm_f32): returns (q [P], lr [P], T) as float64 device tensors.  ``labels`` is a [P, n]
+    uint8 device tensor (non-zero: element belongs to sample 1 under that labeling); any P (the C entry
+    point takes 128 labelings per pass)."""
+    cols, pooled = N.as_f32(cols, "cols"), N.as_f32(pooled, "pooled")
+    if labels.dtype != torch.uint8 or labels.dim() != 2 or labels.shape[1] != pooled.shape[0]:
+        raise ValueError("labels must be a [P, n] uint8 tensor")
+    if not labels.is_cuda:
+        raise N.LvaeError("labels must live on the GPU")
+    labels = labels.contiguous()
+    nc, n, D, P = cols.shape[0], pooled.shape[0], pooled.shape[1], labels.shape[0]
+    dev = pooled.device
+    arr, nalpha = N.host_floats(alphas)
+    q = torch.empty(P, dtype=torch.float64, device=dev)
+    lr = torch.empty(P, dtype=torch.float64, device=dev)
+    tot = None
+    with torch.cuda.device(dev):
+        nbytes = N._i64(0)
+        N.check(N.lib().lvae_mmd_perm_workspace_bytes(nc, n, D, nbytes))
+        ws = N.workspace(nbytes.value, dev)
+        for p0 in range(0, P, 128):
+            lab = labels[p0:p0 + 128]
+            pp = lab.shape[0]
+            out = torch.empty(2 * pp + 1, dtype=torch.float64, device=dev)
+            N.check(N.lib().lvae_mmd_perm_f32(N.ptr(cols), nc, int(col_offset), N.ptr(pooled), n, D, N.ptr(lab),
+                                              pp, arr, nalpha, float(dist_eps), N.ptr(out), N.ptr(ws),
+                                              nbytes.value, N.stream_ptr(dev)))
+            q[p0:p0 + pp] = out[:pp]
+            lr[p0:p0 + pp] = out[pp:2 * pp]
+            tot = out[2 * pp]
+    return q, lr, tot
+
+
+def permutation_labels(n1, n2, n_permutations, device, generator=None):
+    """[1 + n_permutations, n1 + n2] uint8: row 0 is the observed labeling (first n1 elements in sample
+    1), the others are uniformly random relabelings with exactly n1 ones."""
+    n = n1 + n2
+    labels = torch.zeros(1 + n_permutations, n, dtype=torch.uint8, device=device)
+    labels[0, :n1] = 1
+    for p in range(n_permutations):
+        perm = torch.randperm(n, device=device, generator=generator)
+        labels[1 + p, perm[:n1]] = 1
+    return labels
+
+
+def permutation_statistics(q, lr, tot, n1, n2):
+    """Statistic of every labeling from its (q, lr) and the total T (float64 tensors)."""
+    k11 = q
+    k12 = lr - q
+    k22 = tot - 2.0 * lr + q
+    return k11 / (n1 * (n1 - 1.0)) + k22 / (n2 * (n2 - 1.0)) - 2.0 * k12 / (float(n1) * float(n2))
+
+
+def mmd_permutation_test(sample_1, sample_2, alphas, n_permutations=1000, dist_eps=1e-5, labels=None,
+                         generator=None):
+    """Two-sample permutation test on the unbiased Gaussian-kernel MMD (torch_two_sample
+    MMDStatistic.pval restated without the n x n matrix; PARITY UNPINNED).  Returns a dict: ``statistic``
+    (observed), ``statistics`` [n_permutations] (float64, one per relabeling) and ``pval`` = fraction of
+    relabelings whose statistic is >= the observed one.  ``labels`` ([P, n] uint8, row 0 = observed) may
+    be injected for reproducibility."""
+    s1, s2 = N.as_f32(sample_1, "sample_1"), N.as_f32(sample_2, "sample_2")
+    n1, n2 = s1.shape[0], s2.shape[0]
+    pooled = torch.cat((s1, s2), 0).contiguous()
+    if labels is None:
+        labels = permutation_labels(n1, n2, n_permutations, pooled.device, generator)
+    q, lr, tot = mmd_permutation_sums(pooled, 0, pooled, labels, alphas, dist_eps)
+    stats = permutation_statistics(q, lr, tot, n1, n2)
+    return {"statistic": stats[0], "statistics": stats[1:], "pval": (stats[1:] >= stats[0]).double().mean()}
+
+
 def maximum_mean_discrepancy(latent_z, prior_sample=None):
     """loss_and_optimisation.py:46-60: biased RBF MMD between a standard-normal draw x and latent_z:
     mean(Kxx) + mean(Kyy) - 2 mean(Kxy).  The reference draws ``x = randn_like(latent_z)`` inside (:53);

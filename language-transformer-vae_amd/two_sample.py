@@ -4,7 +4,8 @@
 PARITY UNPINNED: josipd/torch-two-sample is an un-vendored submodule with no pinned revision
 (.gitmodules:4-6); this follows its published algorithm -- pooled Euclidean distances
 sqrt(1e-5 + |a.a + b.b - 2 a.b|), kernel sum_alpha exp(-alpha d^2), unbiased statistic with the
-diagonals removed.  ``pval`` (never called by the reference) is not provided.
+diagonals removed.  ``pval`` (never called by the reference) runs the permutation test from the samples
+of the last call through the fused kernels; an arbitrary kernel matrix is not accepted.
 """
 import torch
 
@@ -25,9 +26,20 @@ class MMDStatistic:
     def __call__(self, sample_1, sample_2, alphas, ret_matrix=False):
         if sample_1.shape[0] != self.n_1 or sample_2.shape[0] != self.n_2:
             raise ValueError("sample sizes differ from the ones the statistic was built for")
+        self._last = (sample_1, sample_2, list(alphas))
         out = E.mmd_rbf(sample_1, sample_2, list(alphas), PDIST_EPS, unbiased=True)
         mmd = out[0].float()
         if ret_matrix:
             s12 = torch.cat((N.as_f32(sample_1, "sample_1"), N.as_f32(sample_2, "sample_2")), 0)
             return mmd, E._kernel_matrix(s12, s12, list(alphas), PDIST_EPS)
         return mmd
+
+    def pval(self, distances=None, n_permutations=1000, generator=None):
+        """Permutation-test p-value for the samples of the last ``__call__`` (torch-two-sample passes the
+        kernel matrix returned with ``ret_matrix=True``; here it is only a token -- the n x n matrix is
+        never read, the label sums are regenerated from the samples on the matrix cores)."""
+        if getattr(self, "_last", None) is None:
+            raise RuntimeError("call the statistic on two samples first")
+        s1, s2, alphas = self._last
+        return float(E.mmd_permutation_test(s1, s2, alphas, n_permutations, PDIST_EPS,
+                                            generator=generator)["pval"])

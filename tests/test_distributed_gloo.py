@@ -159,3 +159,69 @@ def test_sharded_mmd_world2():
         assert abs(biased["mmd"] - want_biased) <= 1e-9 * max(1.0, abs(want_biased)), (biased, want_biased)
         assert tts["n1"] == n1 and tts["n2"] == n2
     assert results[0][1] == results[1][1]
+
+
+def _oracle_permutation_sums(cols, col_offset, pooled, labels, alphas, dist_eps):
+    c64, p64 = cols.numpy().astype(np.float64), pooled.numpy().astype(np.float64)
+    d2 = dist_eps + np.abs((c64 ** 2).sum(1)[:, None] + (p64 ** 2).sum(1)[None] - 2.0 * c64 @ p64.T)
+    K = sum(np.exp(-al * d2) for al in alphas if al > 0)
+    i = np.arange(c64.shape[0])
+    K[i, i + col_offset] = 0.0
+    L = (labels.numpy() != 0).astype(np.float64)            # [P, n]
+    Lc = L[:, col_offset:col_offset + c64.shape[0]]          # [P, nc]
+    q = np.einsum("pc,cr,pr->p", Lc, K, L)
+    r = K.sum(1)
+    return torch.from_numpy(q), torch.from_numpy(Lc @ r), torch.tensor(r.sum())
+
+
+def _perm_worker(rank, world, port, n1, n2, D, P, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lvae import distributed as LD
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((n1, D)).astype(np.float32)
+    y = (0.8 * rng.standard_normal((n2, D)) + 0.2).astype(np.float32)
+    lab = np.zeros((P + 1, n1 + n2), dtype=np.uint8)
+    lab[0, :n1] = 1
+    for p in range(P):
+        lab[1 + p, rng.permutation(n1 + n2)[:n1]] = 1
+    xlo, xhi = LD.shard_bounds(n1, world, rank)
+    ys = y[:n2 // 4] if rank == 0 else y[n2 // 4:]
+    out = LD.sharded_mmd_permutation_test(torch.from_numpy(x[xlo:xhi].copy()), torch.from_numpy(ys.copy()),
+                                          [0.1 * i for i in range(15)], torch.from_numpy(lab), 1e-5,
+                                          permutation_sums=_oracle_permutation_sums)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_mmd_permutation_world2():
+    from oracle import oracle_np as onp
+    n1, n2, D, P, world = 41, 36, 8, 12, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_perm_worker, args=(r, world, port, n1, n2, D, P, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((n1, D)).astype(np.float32)
+    y = (0.8 * rng.standard_normal((n2, D)) + 0.2).astype(np.float32)
+    lab = np.zeros((P + 1, n1 + n2), dtype=np.uint8)
+    lab[0, :n1] = 1
+    for p in range(P):
+        lab[1 + p, rng.permutation(n1 + n2)[:n1]] = 1
+    alphas = [0.1 * i for i in range(15)]
+    obs, K = onp.mmd_statistic_tts(x, y, alphas, ret_matrix=True)
+    ref = onp.mmd_permutation_stats(K, n1, n2, 1 - lab)
+    for rank, out in results:
+        assert abs(out["statistic"] - obs) <= 1e-9 * max(1.0, abs(obs))
+        np.testing.assert_allclose(out["statistics"], ref[1:], rtol=1e-8, atol=1e-11)
+        assert abs(out["pval"] - float((ref[1:] >= ref[0]).mean())) < 1e-12
+    assert results[0][1] == results[1][1]

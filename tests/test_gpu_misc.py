@@ -186,6 +186,47 @@ def test_kernel_sum_blocks(na, nb, D, off):
             assert float(tot2) == float(tot)
 
 
+@pytest.mark.parametrize("n1,n2,D,P", [(300, 340, 32, 20), (257, 190, 64, 130), (1000, 1500, 16, 9),
+                                         (200, 150, 128, 5), (2048, 2048, 32, 33)])
+def test_mmd_permutation_test_unpinned(n1, n2, D, P):
+    """Permutation statistics (PARITY UNPINNED, like the statistic itself) against the float64 NumPy
+    restatement evaluated on the dense kernel matrix.  The statistic is a difference of O(1) means, so the
+    error is judged against the kernel scale, and the observed statistic against 1e-4."""
+    from lvae import estimators as E
+    rng = np.random.default_rng(n1 + D + P)
+    a = rng.standard_normal((n1, D)).astype(np.float32)
+    b = (rng.standard_normal((n2, D)) * 0.9 + 0.15).astype(np.float32)
+    alphas = [0.1 * i for i in range(15)] if D != 64 else [0.02]
+    ref_obs, K = onp.mmd_statistic_tts(a, b, alphas, ret_matrix=True)
+    labels = E.permutation_labels(n1, n2, P, "cuda", torch.Generator(device="cuda").manual_seed(5))
+    assert labels.shape == (P + 1, n1 + n2) and bool((labels.sum(1) == n1).all())
+    lab_np = labels.cpu().numpy()
+    ref = onp.mmd_permutation_stats(K, n1, n2, 1 - lab_np)      # oracle convention: 0 -> sample 1
+    out = E.mmd_permutation_test(dev(a), dev(b), alphas, labels=labels)
+    got = np.concatenate([[float(out["statistic"])], out["statistics"].cpu().numpy()])
+    assert abs(ref[0] - ref_obs) <= 1e-12 * max(1.0, abs(ref_obs))
+    assert abs(got[0] - ref_obs) <= 1e-4 * abs(ref_obs)
+    kscale = len([x for x in alphas if x > 0])
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-6 * kscale)
+    want_p = float((ref[1:] >= ref[0]).mean())
+    assert abs(float(out["pval"]) - want_p) <= 1.0 / P + 1e-12
+    # the same through the torch-two-sample style object
+    from lvae.two_sample import MMDStatistic
+    st = MMDStatistic(n1, n2)
+    st(dev(a), dev(b), alphas)
+    pv = st.pval(None, n_permutations=16)
+    assert 0.0 <= pv <= 1.0
+    # column-sharded evaluation adds up to the same sums
+    pooled = torch.cat((dev(a), dev(b)), 0)
+    q, lr, tot = E.mmd_permutation_sums(pooled, 0, pooled, labels, alphas, 1e-5)
+    cut = (n1 + n2) // 3
+    q1, lr1, t1 = E.mmd_permutation_sums(pooled[:cut].contiguous(), 0, pooled, labels, alphas, 1e-5)
+    q2, lr2, t2 = E.mmd_permutation_sums(pooled[cut:].contiguous(), cut, pooled, labels, alphas, 1e-5)
+    np.testing.assert_allclose((q1 + q2).cpu().numpy(), q.cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose((lr1 + lr2).cpu().numpy(), lr.cpu().numpy(), rtol=1e-9)
+    assert abs(float(t1 + t2) - float(tot)) <= 1e-9 * float(tot)
+
+
 def test_get_tts_mmmd_and_encode_tail():
     from lvae import encoder_ops as EO
     from lvae import estimators as E
