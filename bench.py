@@ -167,7 +167,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s",
                          "frac": (achieved / FP32_MFMA_PEAK_TFLOPS) if achieved else None,
-                         "traffic": traffic, "kernel": "pair_lse_mfma_kernel<32,2,2,false>",
+                         "traffic": traffic, "kernel": "pair_lse_mfma_kernel<32,2,2,false,4> (fixed-reference logsumexp epilogue)",
                          "kernel_ms_avg": k_avg_ms, "launches": k_n.value,
                          "flops_per_launch": 4.0 * D * pairs_rank},
             "results": {k: v for k, v in state["out"].items() if isinstance(v, float)},

@@ -15,7 +15,8 @@ int lvae_launch_prep_dparams(const float* mu, const float* spread, int spread_ki
 int lvae_launch_finalize(const float2* partial, int nsplit, int64_t cpad, int64_t C,
                          const float* colbias, float log_norm, float* out, float* out_max,
                          float* out_sum, const PairHeader* hdr, float cond_limit, int use_if_above,
-                         hipStream_t st);
+                         int use_ref, int* flags_out, const int* flags_in, int group_cols, hipStream_t st);
+int lvae_launch_lse_shift_bias(float* rbias, int64_t n, PairHeader* hdr, hipStream_t st);
 int lvae_launch_finalize_pm(const float2* partial, int nsplit, int64_t cpad, int64_t C, int D, int DC,
                             float log_norm, float* out, hipStream_t st);
 int lvae_launch_pair_lse_mfma(const PairPlan& p, const float* rfrag, const float* rbias,
@@ -42,7 +43,7 @@ int lvae_launch_latent_sums(const float* z, const float* mu, const float* logvar
 
 int lvae_launch_pair_mfma(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                           float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
-                          bool excl, int64_t excl_offset, int epi, hipStream_t st);
+                          bool excl, int64_t excl_offset, int epi, const int* redo_flags, hipStream_t st);
 int lvae_launch_finalize_ksum(const double* partial, int nsplit, int64_t cpad, int64_t C, double* out,
                               hipStream_t st);
 int lvae_launch_kl(const float* mu, const float* logvar, int64_t n, int D, float lambda, float* kl_elem,
@@ -232,10 +233,23 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
 
     const bool gated = want_joint && joint_path == LVAE_PATH_AUTO;
     const float limit = gated ? LVAE_COND_LIMIT : -1.0f;
+    // MFMA path: a first pass against a fixed reference (no running maximum: every term is bounded by
+    // the largest row bias), then -- for the rare columns whose total underflowed that reference -- a
+    // redo of their workgroups with the running-maximum kernel.  All decided on the device.
+    const bool fixed_ref = need_mfma && N <= (1LL << 24);
+    int* redo = (int*)(base + p.off_redo);
+    const int group_cols = 128 * p.NCB;
+    if (need_mfma) {
+        LVAE_HIP(hipMemsetAsync(redo, 0, (size_t)(p.cpad / 128 + 1) * sizeof(int), st));
+        if (fixed_ref) {
+            rc = lvae_launch_lse_shift_bias(rbias, p.nblk * 32, hdr, st);
+            if (rc) return rc;
+        }
+    }
     hipEvent_t prof_stop = prof_mark(st, nullptr);
     if (need_mfma) {
-        rc = lvae_launch_pair_lse_mfma(p, rfrag, rbias, cop, partial, hdr, limit, 0, exclude_diag != 0,
-                                       diag_offset, st);
+        rc = lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, limit, 0, exclude_diag != 0, diag_offset,
+                                   fixed_ref ? 4 : 0, nullptr, st);
         if (rc) return rc;
     }
     if (need_direct) {
@@ -251,12 +265,21 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
         // exits on the same device-side test, so the outputs are written once.
         if (joint_path != LVAE_PATH_DIRECT) {
             rc = lvae_launch_finalize(partial, p.nsplit, p.cpad, M, nullptr, log_norm, log_qz, row_max,
-                                      row_sum, hdr, limit, 0, st);
+                                      row_sum, hdr, limit, 0, fixed_ref ? 1 : 0, fixed_ref ? redo : nullptr,
+                                      nullptr, group_cols, st);
             if (rc) return rc;
+            if (fixed_ref) {
+                rc = lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, limit, 0, exclude_diag != 0,
+                                           diag_offset, 0, redo, st);
+                if (rc) return rc;
+                rc = lvae_launch_finalize(partial, p.nsplit, p.cpad, M, nullptr, log_norm, log_qz, row_max,
+                                          row_sum, hdr, limit, 0, 1, nullptr, redo, group_cols, st);
+                if (rc) return rc;
+            }
         }
         if (joint_path != LVAE_PATH_MFMA) {
             rc = lvae_launch_finalize(dpartial, p.dsplit, p.cpad, M, nullptr, log_norm, log_qz, row_max,
-                                      row_sum, hdr, limit, 1, st);
+                                      row_sum, hdr, limit, 1, 0, nullptr, nullptr, group_cols, st);
             if (rc) return rc;
         }
     }
@@ -317,7 +340,7 @@ extern "C" int lvae_qz_estimate_f32(const float* z, const float* mu, const float
     rc = lvae_launch_pair_lse_mfma(p, rfrag, rbias, cop, partial, hdr, -1.f, 0, false, 0, st);
     if (rc) return rc;
     return lvae_launch_finalize(partial, p.nsplit, p.cpad, N, colbias, log_norm, out, nullptr, nullptr,
-                                hdr, -1.f, 0, st);
+                                hdr, -1.f, 0, 0, nullptr, nullptr, 1, st);
 }
 
 // ---- per-sample densities / sampling / IW ----------------------------------------------------------
@@ -530,7 +553,7 @@ static int ksum_pass(const float* a, int64_t na, const float* b, int64_t nb, int
     if (rc) return rc;
     rc = lvae_launch_prep(1, false, a, nullptr, 0, na, p.cpad, D, p.DP, hdr, 1, cop, nullptr, nullptr, p.DC, st);
     if (rc) return rc;
-    rc = lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, -1.f, 0, excl, 0, epi, st);
+    rc = lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, -1.f, 0, excl, 0, epi, nullptr, st);
     if (rc) return rc;
     return lvae_launch_finalize_ksum((const double*)partial, p.nsplit, p.cpad, na, out, st);
 }
@@ -613,7 +636,7 @@ extern "C" int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, i
         if (rc) return rc;
         rc = lvae_launch_pair_mfma(p, (float*)(base + p.off_rfrag), (float*)(base + p.off_rbias),
                                    (float*)(base + p.off_cop), partial, hdr, -1.f, 0, exclude_diag != 0,
-                                   diag_offset, ksum_epi(kp), st);
+                                   diag_offset, ksum_epi(kp), nullptr, st);
         if (rc) return rc;
     }
     return lvae_launch_ksum_columns((const double*)partial, p.nsplit, p.cpad, na, nb, exclude_diag != 0,

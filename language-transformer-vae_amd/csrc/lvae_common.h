@@ -12,6 +12,15 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// float -> unsigned key with the same ordering (for atomicMax on signed floats) and back
+__device__ __forceinline__ unsigned lvae_float_key(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float lvae_key_float(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---- error plumbing (lvae_api.hip owns the storage) -------------------------------------------

@@ -21,6 +21,7 @@
 #include "pair_plan.h"
 
 #define LSE_THR 8.0f
+#define LSE_BIG 256.0f      // 2^LSE_THR
 
 // s_waitcnt vmcnt(n) for a small n known after unrolling
 __device__ __forceinline__ void wait_vmcnt(int n) {
@@ -61,7 +62,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
                      const float* __restrict__ cop, float2* __restrict__ partial,
                      const PairHeader* __restrict__ hdr, float cond_limit, int use_if_above,
                      int64_t nblk, int64_t blk_per_split, int64_t cpad, int64_t excl_offset,
-                     PermArgs pa) {
+                     PermArgs pa, const int* __restrict__ redo_flags) {
     static_assert(!PERM || (NCB == 1 && (EPI == 1 || EPI == 2)), "PERM needs NCB == 1 and a polynomial epilogue");
     // Path gate: the conditioning estimate written by prep decides between this kernel and the direct
     // one without a host round trip (both are launched; the unselected one exits here).
@@ -69,6 +70,8 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
         const float cond = __uint_as_float(hdr->cond_bits);
         if ((cond > cond_limit) != (use_if_above != 0)) return;
     }
+    // redo pass of the fixed-reference logsumexp: only the flagged workgroups have work
+    if (redo_flags && redo_flags[blockIdx.x] == 0) return;
     constexpr int NQ = DP / 4;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -177,18 +180,23 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (want == 8 * g + 4 * h + e) acc[cb][4 * g + e] = EPI >= 1 ? INFINITY : -INFINITY;
+                        if (want == 8 * g + 4 * h + e) acc[cb][4 * g + e] = (EPI >= 1 && EPI <= 3) ? INFINITY : -INFINITY;
             }
         }
     };
 
     // Epilogue of one 32x32 tile, cut into EPI_MS micro-slices of <= ~10 VALU instructions so that
     // each one issues in the shadow of one MFMA of the NEXT block (64 cycles of matrix-pipe time):
-    //   0: max of elements 0..7        1: max of 8..15, lazy rescale of the running (max, sum)
-    //   2..9: two exponentials each, added to the running sum.
+    //   0..7: two exponentials each (packed subtract / add), summed into the tile sum
+    //   8: tile sum -> running sum, or the rare redo against a new maximum.
     // (EPI 1: 17 micro-slices: one pair each, the last one folds the tile sum into float64.)
-    constexpr int EPI_MS = EPI >= 1 ? 17 : 10;
-    float tmax[NCB];
+    constexpr int EPI_MS = EPI == 4 ? 8 : (EPI >= 1 ? 17 : 9);
+    f32x2 m2[NCB], kt2[NCB];            // EPI 0: minus the running max, twice (packed operand); tile sum in flight
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        m2[cb] = (f32x2){-LSE_MINIT, -LSE_MINIT};
+        kt2[cb] = (f32x2){0.f, 0.f};
+    }
     float kv[PERM ? 16 : 1];            // PERM: the kernel values of the tile whose epilogue is running
     // Kernel-sum parameters, read once into (scalar) registers: EPI 1 = one bandwidth (c0 + c1*t),
     // EPI 2 = polynomial of degree <= 16 in t, fully unrolled Horner (unused high coefficients are 0),
@@ -197,7 +205,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     float kc[KC];
     float k_eps = 0.f, k_nbase = 0.f;
     int k_n = 0;
-    if (EPI >= 1) {
+    if (EPI >= 1 && EPI <= 3) {
         const KsumParams* kp = &hdr->ksum;
         k_eps = kp->eps;
         k_nbase = kp->nbase;
@@ -224,7 +232,14 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
         }
     };
     auto epi_micro = [&](const f32x16 (&prev)[NCB], int cb, int ms) {
-        if (EPI >= 1) {
+        if (EPI == 4) {
+            // fixed reference (folded into the row biases by lse_shift_bias_kernel): every term is at
+            // most 2^LSE_HEADROOM, so the tile is two exponentials and one packed add per slice
+            f32x2 e;
+            e.x = lvae_exp2(prev[cb][2 * ms]);
+            e.y = lvae_exp2(prev[cb][2 * ms + 1]);
+            kt2[cb] += e;
+        } else if (EPI >= 1) {
             if (ms < 16) {
                 const float kval = kfun(prev[cb][ms]);
                 kt[cb] += kval;
@@ -233,27 +248,45 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
                 ks[cb] += (double)kt[cb];
                 kt[cb] = 0.f;
             }
-        } else if (ms == 0) {
-            float t = prev[cb][0];
-#pragma unroll
-            for (int e = 1; e < 8; ++e) t = fmaxf(t, prev[cb][e]);
-            tmax[cb] = t;
-        } else if (ms == 1) {
-            float t = tmax[cb];
-#pragma unroll
-            for (int e = 8; e < 16; ++e) t = fmaxf(t, prev[cb][e]);
-            const float mn = (t > m[cb] + LSE_THR) ? t : m[cb];
-            s[cb] *= lvae_exp2(m[cb] - mn);
-            m[cb] = mn;
-        } else {
-            const int e = 2 * (ms - 2);
-#if defined(LVAE_DBG_EPI_ADDONLY)
-            s[cb] += prev[cb][e] + prev[cb][e + 1];
-#elif defined(LVAE_DBG_EPI_NOSUB)
-            s[cb] += lvae_exp2(prev[cb][e]) + lvae_exp2(prev[cb][e + 1]);
+        } else if (ms < 8) {
+            // two pairs per slice on the packed fp32 pipe: subtract the running max, exponentiate,
+            // accumulate the tile sum (the first slice starts it)
+            const f32x2 pr = {prev[cb][2 * ms], prev[cb][2 * ms + 1]};
+            f32x2 x;    // (the compiler would split this packed add into two scalar ones)
+            asm("v_pk_add_f32 %0, %1, %2" : "=v"(x) : "v"(pr), "v"(m2[cb]));
+            f32x2 e;
+#ifdef LVAE_DBG_NOEXP
+            e = x;
 #else
-            s[cb] += lvae_exp2(prev[cb][e] - m[cb]) + lvae_exp2(prev[cb][e + 1] - m[cb]);
+            e.x = lvae_exp2(x.x);
+            e.y = lvae_exp2(x.y);
 #endif
+            if (ms == 0) kt2[cb] = e;
+            else kt2[cb] += e;
+        } else {
+            // Lazy running max without a max tree: all terms are positive, so a tile sum below 2^LSE_THR
+            // proves that no term exceeded the running max by LSE_THR bits and the sum is simply added.
+            // Otherwise (the first tile, or a rare jump of the maximum; inf/NaN land here too) the whole
+            // wave redoes the tile against the true maximum.
+            const float ts = kt2[cb].x + kt2[cb].y;
+#ifdef LVAE_DBG_NOBRANCH
+            if (false) {
+#else
+            if (__builtin_expect(__any(!(ts < LSE_BIG)), 0)) {
+#endif
+                float t = prev[cb][0];
+#pragma unroll
+                for (int e = 1; e < 16; ++e) t = fmaxf(t, prev[cb][e]);
+                const float mn = fmaxf(m[cb], t);
+                float acc = s[cb] * lvae_exp2(m[cb] - mn);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc += lvae_exp2(prev[cb][e] - mn);
+                s[cb] = acc;
+                m[cb] = mn;
+                m2[cb] = (f32x2){-mn, -mn};
+            } else {
+                s[cb] += ts;
+            }
         }
     };
     // ---- PERM: label-permutation accumulators --------------------------------------------------
@@ -441,6 +474,15 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     }
 
     // merge the two half-waves (same column, complementary rows) and publish
+    if (EPI == 4) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const float sv = kt2[cb].x + kt2[cb].y;
+            const float ss = sv + __shfl_xor(sv, 32, 64);
+            if (h == 0) partial[(int64_t)blockIdx.y * cpad + col0 + cb * 32 + r] = make_float2(0.f, ss);
+        }
+        return;
+    }
     if (EPI >= 1) {
         double* kpartial = reinterpret_cast<double*>(partial);
 #pragma unroll
@@ -463,13 +505,13 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
 template <int DP, int NCB, int WPS>
 static int launch_t(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                     float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
-                    bool excl, int64_t excl_offset, int epi, hipStream_t st) {
+                    bool excl, int64_t excl_offset, int epi, const int* redo_flags, hipStream_t st) {
     const dim3 grid((unsigned)(p.cpad / (4 * 32 * NCB)), (unsigned)p.nsplit);
     const PermArgs pa{};
 #define LVAE_PAIR(X, E)                                                                              \
     hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, NCB, WPS, X, E>), grid, dim3(256), 0, st, rfrag, rbias, \
                        cop, partial, hdr, cond_limit, use_if_above, p.nblk, p.blk_per_split, p.cpad,  \
-                       excl_offset, pa)
+                       excl_offset, pa, redo_flags)
     switch (epi * 2 + (excl ? 1 : 0)) {
         case 0: LVAE_PAIR(false, 0); break;
         case 1: LVAE_PAIR(true, 0); break;
@@ -479,6 +521,8 @@ static int launch_t(const PairPlan& p, const float* rfrag, const float* rbias, c
         case 5: LVAE_PAIR(true, 2); break;
         case 6: LVAE_PAIR(false, 3); break;
         case 7: LVAE_PAIR(true, 3); break;
+        case 8: LVAE_PAIR(false, 4); break;
+        case 9: LVAE_PAIR(true, 4); break;
         default: return lvae_set_error(LVAE_ERR_INVALID, "bad epilogue id %d", epi);
     }
 #undef LVAE_PAIR
@@ -487,19 +531,21 @@ static int launch_t(const PairPlan& p, const float* rfrag, const float* rbias, c
 }
 
 // cond_limit < 0: run unconditionally.  Otherwise run iff (cond > cond_limit) == use_if_above.
-// epi 0: logsumexp epilogue; 1/2/3: kernel-matrix column sums (float64 partials; parameters in
-// hdr->ksum: single bandwidth / polynomial of degree <= 16 / arbitrary bandwidths).
+// epi 0: logsumexp epilogue with a running maximum; 4: logsumexp against the fixed reference folded into
+// the row biases; 1/2/3: kernel-matrix column sums (float64 partials; parameters in hdr->ksum: single
+// bandwidth / polynomial of degree <= 16 / arbitrary bandwidths).
+// redo_flags (may be NULL): one int per workgroup column group; workgroups whose flag is 0 exit.
 int lvae_launch_pair_mfma(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                           float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
-                          bool excl, int64_t excl_offset, int epi, hipStream_t st) {
+                          bool excl, int64_t excl_offset, int epi, const int* redo_flags, hipStream_t st) {
     if (p.cpad % (4 * 32 * p.NCB) != 0)
         return lvae_set_error(LVAE_ERR_INVALID, "pair plan: cpad %lld not a multiple of the tile",
                               (long long)p.cpad);
     switch (p.DP) {
-        case 16: return launch_t<16, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, st);
-        case 32: return launch_t<32, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, st);
-        case 64: return launch_t<64, 1, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, st);
-        case 128: return launch_t<128, 1, 1>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, st);
+        case 16: return launch_t<16, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, st);
+        case 32: return launch_t<32, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, st);
+        case 64: return launch_t<64, 1, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, st);
+        case 128: return launch_t<128, 1, 1>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, st);
         default:
             return lvae_set_error(LVAE_ERR_UNSUPPORTED, "MFMA path needs D <= 128 (got D=%d)", p.D);
     }
@@ -510,7 +556,7 @@ int lvae_launch_pair_lse_mfma(const PairPlan& p, const float* rfrag, const float
                               float cond_limit, int use_if_above, bool excl, int64_t excl_offset,
                               hipStream_t st) {
     return lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl,
-                                 excl_offset, 0, st);
+                                 excl_offset, 0, nullptr, st);
 }
 
 // Kernel-matrix column sums plus label-permutation sums (see PERM above); diagonal pairs (reduced row ==
@@ -522,10 +568,10 @@ static int launch_perm_t(const PairPlan& p, const float* rfrag, const float* rbi
     const dim3 grid((unsigned)(p.cpad / (4 * 32)), (unsigned)p.nsplit);
     if (epi == 1)
         hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 1, true>), grid, dim3(256), 0, st, rfrag, rbias,
-                           cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa);
+                           cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr);
     else
         hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 2, true>), grid, dim3(256), 0, st, rfrag, rbias,
-                           cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa);
+                           cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }

@@ -7,6 +7,10 @@
 // Parameters of the kernel-matrix epilogue: f(v) = sum_k exp(-alpha_k v), v = eps + |d2|.
 // poly: c[0..n] are the coefficients of a polynomial in t = exp2(v * nbase); else c[k] = -alpha_k*log2e.
 #define LVAE_KSUM_MAX 32
+// Fixed-reference logsumexp: row biases are shifted so that every term is <= 2^LSE_HEADROOM; a column
+// whose total stays below 2^LSE_FLOOR_LOG2 is redone with the running-maximum kernel.
+#define LSE_HEADROOM 100.0f
+#define LSE_FLOOR 8.2718061e-25f     // 2^-80
 struct KsumParams {
     int poly;
     int n;
@@ -19,7 +23,9 @@ struct KsumParams {
 struct PairHeader {
     double colsum[128];      // per-dimension sum of the posterior means (centering shift * R_gauss)
     unsigned int cond_bits;  // float bits of max_j conditioning estimate (non-negative -> uint order)
-    unsigned int pad_[63];
+    unsigned int cmax_key;   // order-preserving key of the largest density normaliser max_j -0.5 log2 prod_d(2 pi var_jd)
+    float lse_ref;           // reference the row biases were shifted by: every term <= 2^LSE_HEADROOM
+    unsigned int pad_[61];
     KsumParams ksum;         // kernel-matrix epilogue parameters (copied in by the MMD entry point)
     unsigned int pad2_[27];
 };
@@ -49,7 +55,7 @@ struct PairPlan {
     int DC;          // padded dim of the direct-path parameters: 16/32/64, or a multiple of 16 above
     // byte offsets into the workspace
     size_t off_hdr, off_rfrag, off_rbias, off_cop, off_colbias, off_partial;
-    size_t off_dparams, off_dpartial, off_dpartial_pm, off_dflags, total;
+    size_t off_dparams, off_dpartial, off_dpartial_pm, off_dflags, off_redo, total;
 };
 
 static inline size_t lvae_align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -96,6 +102,8 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
     if (with_pm) o = lvae_align256(o + (size_t)p.dsplit * p.cpad * p.DC * 2 * sizeof(float));
     p.off_dflags = o;   // redo flags of the prod-marginals fast pass: [dsplit][DC/16][cpad/64]
     if (with_pm) o = lvae_align256(o + (size_t)p.dsplit * (p.DC / 16) * (p.cpad / 64) * sizeof(int));
+    p.off_redo = o;     // redo flags of the fixed-reference logsumexp pass: one int per MFMA workgroup column group
+    o = lvae_align256(o + (size_t)(p.cpad / 128 + 1) * sizeof(int));
     p.total = o;
     return p;
 }

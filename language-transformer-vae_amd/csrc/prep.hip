@@ -69,6 +69,7 @@ prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ sprea
     __shared__ float sm_shift[128];
     __shared__ float sm_c[1024];
     __shared__ float sm_k[1024];
+    __shared__ float sm_n[1024];
     const int NQ = DP >> 2;
     const int tid = threadIdx.x;
     if (tid < DP) sm_shift[tid] = tid < D ? (float)(hdr->colsum[tid] * inv_ngauss) : 0.f;
@@ -79,7 +80,7 @@ prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ sprea
     const int64_t row = blk * 32 + r;
     const bool valid = row < n;
     f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-    float csum = 0.f, cond = 0.f;
+    float csum = 0.f, cond = 0.f, nsum = 0.f;
     if (valid) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -94,6 +95,7 @@ prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ sprea
                     v0[e] = -0.5f * LVAE_LOG2E * p;
                     v1[e] = LVAE_LOG2E * xs * p;
                     csum += xs * xs * p + logvar + LVAE_LOG_2PI;
+                    nsum += logvar + LVAE_LOG_2PI;
                     const float t = 2.0f * fabsf(xs) * sqrtf(p) + 3.0f;
                     cond += 0.5f * t * t;
                     if (dparams) {
@@ -129,19 +131,25 @@ prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ sprea
     if (bias || GAUSS) {
         sm_c[r * NQ + q] = csum;
         sm_k[r * NQ + q] = cond;
+        sm_n[r * NQ + q] = nsum;
         __syncthreads();
         if (q == 0 && row < npad) {
-            float c = 0.f, k = 0.f;
+            float c = 0.f, k = 0.f, nn = 0.f;
             for (int j = 0; j < NQ; ++j) {
                 c += sm_c[r * NQ + j];
                 k += sm_k[r * NQ + j];
+                nn += sm_n[r * NQ + j];
             }
             if (bias) {
                 float b = GAUSS ? -0.5f * LVAE_LOG2E * c : (POINT ? c : 0.f);
                 if (!valid) b = FRAG ? (POINT ? INFINITY : -INFINITY) : 0.f;
                 bias[row] = b;
             }
-            if (GAUSS && valid) atomicMax(&hdr->cond_bits, __float_as_uint(k));
+            if (GAUSS && valid) {
+                atomicMax(&hdr->cond_bits, __float_as_uint(k));
+                // the density's normaliser bounds every term of row `row`: v_ij <= -0.5 log2e sum_d log(2 pi var)
+                atomicMax(&hdr->cmax_key, lvae_float_key(-0.5f * LVAE_LOG2E * nn));
+            }
         }
     }
 }
@@ -168,20 +176,36 @@ __global__ void prep_dparams_kernel(const float* __restrict__ mu, const float* _
     dparams[(row * 3 + 2) * DC + d] = b;
 }
 
+// Fixed-reference logsumexp: shift the row biases by ref = (largest normaliser) - LSE_HEADROOM, so that every
+// term 2^(v_ij - ref) is at most 2^LSE_HEADROOM and the pair kernel needs no running maximum.
+__global__ void __launch_bounds__(256) lse_shift_bias_kernel(float* __restrict__ rbias, int64_t n,
+                                                             PairHeader* hdr) {
+    const float ref = lvae_key_float(hdr->cmax_key) - LSE_HEADROOM;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) rbias[i] -= ref;          // padding rows stay -inf
+    if (i == 0) hdr->lse_ref = ref;
+}
+
 // Merge the per-split (max, sum) partials (base-2 domain) of one kept element into its result.
-//   out      : ln2 * (M + log2 S + colbias) - log_norm
+//   out      : ln2 * (M + log2 S + colbias + ref) - log_norm      (ref = hdr->lse_ref if use_ref)
 //   out_max / out_sum : un-normalised natural-log pair for cross-device combination
+// flags_out: fixed-reference pass -- a column whose total is not >= LSE_FLOOR (underflow, NaN) raises the
+//            redo flag of its MFMA workgroup (group_cols columns per flag);
+// flags_in : redo pass -- only columns whose flag is set are (re)written.
 __global__ void finalize_lse_kernel(const float2* __restrict__ partial, int nsplit, int64_t cpad,
                                     int64_t C, const float* __restrict__ colbias, float log_norm,
                                     float* __restrict__ out, float* __restrict__ out_max,
                                     float* __restrict__ out_sum, const PairHeader* __restrict__ hdr,
-                                    float cond_limit, int use_if_above) {
+                                    float cond_limit, int use_if_above, int use_ref,
+                                    int* __restrict__ flags_out, const int* __restrict__ flags_in,
+                                    int group_cols) {
     if (cond_limit >= 0.f) {   // same path gate as the pair kernels
         const float cond = __uint_as_float(hdr->cond_bits);
         if ((cond > cond_limit) != (use_if_above != 0)) return;
     }
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C) return;
+    if (flags_in && flags_in[i / group_cols] == 0) return;
     float mx = -INFINITY;
     for (int k = 0; k < nsplit; ++k) mx = fmaxf(mx, partial[k * cpad + i].x);
     double s = 0.0;
@@ -189,7 +213,8 @@ __global__ void finalize_lse_kernel(const float2* __restrict__ partial, int nspl
         const float2 p = partial[k * cpad + i];
         if (p.y > 0.f) s += (double)p.y * exp2((double)p.x - (double)mx);
     }
-    const double cb = colbias ? (double)colbias[i] : 0.0;
+    if (flags_out && !(s >= (double)LSE_FLOOR)) flags_out[i / group_cols] = 1;
+    const double cb = (colbias ? (double)colbias[i] : 0.0) + (use_ref ? (double)hdr->lse_ref : 0.0);
     if (out) out[i] = (float)(((double)mx + log2(s) + cb) * LVAE_LN2 - (double)log_norm);
     if (out_max) {
         out_max[i] = (float)(((double)mx + cb) * LVAE_LN2);
@@ -258,10 +283,17 @@ int lvae_launch_prep_dparams(const float* mu, const float* spread, int spread_ki
 int lvae_launch_finalize(const float2* partial, int nsplit, int64_t cpad, int64_t C,
                          const float* colbias, float log_norm, float* out, float* out_max,
                          float* out_sum, const PairHeader* hdr, float cond_limit, int use_if_above,
-                         hipStream_t st) {
+                         int use_ref, int* flags_out, const int* flags_in, int group_cols, hipStream_t st) {
     hipLaunchKernelGGL(finalize_lse_kernel, dim3((unsigned)lvae_ceil_div(C, 256)), dim3(256), 0, st,
                        partial, nsplit, cpad, C, colbias, log_norm, out, out_max, out_sum, hdr,
-                       cond_limit, use_if_above);
+                       cond_limit, use_if_above, use_ref, flags_out, flags_in, group_cols);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+int lvae_launch_lse_shift_bias(float* rbias, int64_t n, PairHeader* hdr, hipStream_t st) {
+    hipLaunchKernelGGL(lse_shift_bias_kernel, dim3((unsigned)lvae_ceil_div(n, 256)), dim3(256), 0, st, rbias, n,
+                       hdr);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }
