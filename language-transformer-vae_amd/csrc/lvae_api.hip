@@ -43,7 +43,7 @@ int lvae_launch_latent_sums(const float* z, const float* mu, const float* logvar
 
 int lvae_launch_pair_mfma(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                           float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
-                          bool excl, int64_t excl_offset, int epi, const int* redo_flags, hipStream_t st);
+                          bool excl, int64_t excl_offset, int epi, const int* redo_flags, int sym, hipStream_t st);
 int lvae_launch_finalize_ksum(const double* partial, int nsplit, int64_t cpad, int64_t C, double* out,
                               hipStream_t st);
 int lvae_launch_kl(const float* mu, const float* logvar, int64_t n, int D, float lambda, float* kl_elem,
@@ -249,7 +249,7 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     hipEvent_t prof_stop = prof_mark(st, nullptr);
     if (need_mfma) {
         rc = lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, limit, 0, exclude_diag != 0, diag_offset,
-                                   fixed_ref ? 4 : 0, nullptr, st);
+                                   fixed_ref ? 4 : 0, nullptr, 0, st);
         if (rc) return rc;
     }
     if (need_direct) {
@@ -270,7 +270,7 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
             if (rc) return rc;
             if (fixed_ref) {
                 rc = lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, limit, 0, exclude_diag != 0,
-                                           diag_offset, 0, redo, st);
+                                           diag_offset, 0, redo, 0, st);
                 if (rc) return rc;
                 rc = lvae_launch_finalize(partial, p.nsplit, p.cpad, M, nullptr, log_norm, log_qz, row_max,
                                           row_sum, hdr, limit, 0, 1, nullptr, redo, group_cols, st);
@@ -528,7 +528,7 @@ extern "C" int lvae_mmd_workspace_bytes(int64_t n1, int64_t n2, int D, int64_t* 
     LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
     LVAE_CHECK_ARG(n1 >= 2 && n2 >= 2 && D >= 1, "need n1, n2 >= 2 and D >= 1");
     const int64_t nm = n1 > n2 ? n1 : n2;
-    const PairPlan p = lvae_make_pair_plan(nm, nm, D, false);
+    const PairPlan p = lvae_make_pair_plan(nm, nm, D, false, 0, true);
     *out_bytes = (int64_t)(p.total + 256);
     return LVAE_OK;
 }
@@ -541,7 +541,7 @@ static int ksum_epi(const KsumParams& kp) {
 
 static int ksum_pass(const float* a, int64_t na, const float* b, int64_t nb, int D, bool excl, int epi,
                      void* ws, double* out, hipStream_t st) {
-    const PairPlan p = lvae_make_pair_plan(nb, na, D, false);
+    const PairPlan p = lvae_make_pair_plan(nb, na, D, false, 0, a == b);
     char* base = (char*)ws;
     PairHeader* hdr = (PairHeader*)(base + p.off_hdr);
     float* rfrag = (float*)(base + p.off_rfrag);
@@ -553,7 +553,7 @@ static int ksum_pass(const float* a, int64_t na, const float* b, int64_t nb, int
     if (rc) return rc;
     rc = lvae_launch_prep(1, false, a, nullptr, 0, na, p.cpad, D, p.DP, hdr, 1, cop, nullptr, nullptr, p.DC, st);
     if (rc) return rc;
-    rc = lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, -1.f, 0, excl, 0, epi, nullptr, st);
+    rc = lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, -1.f, 0, excl, 0, epi, nullptr, a == b ? 1 : 0, st);
     if (rc) return rc;
     return lvae_launch_finalize_ksum((const double*)partial, p.nsplit, p.cpad, na, out, st);
 }
@@ -571,7 +571,7 @@ extern "C" int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int6
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int64_t nm = n1 > n2 ? n1 : n2;
-    const PairPlan pmax = lvae_make_pair_plan(nm, nm, D, false);
+    const PairPlan pmax = lvae_make_pair_plan(nm, nm, D, false, 0, true);
     rc = check_ws(ws, ws_bytes, pmax.total + 256);
     if (rc) return rc;
     PairHeader* hdr = (PairHeader*)ws;
@@ -636,7 +636,7 @@ extern "C" int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, i
         if (rc) return rc;
         rc = lvae_launch_pair_mfma(p, (float*)(base + p.off_rfrag), (float*)(base + p.off_rbias),
                                    (float*)(base + p.off_cop), partial, hdr, -1.f, 0, exclude_diag != 0,
-                                   diag_offset, ksum_epi(kp), nullptr, st);
+                                   diag_offset, ksum_epi(kp), nullptr, 0, st);
         if (rc) return rc;
     }
     return lvae_launch_ksum_columns((const double*)partial, p.nsplit, p.cpad, na, nb, exclude_diag != 0,

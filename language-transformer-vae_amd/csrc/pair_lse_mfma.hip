@@ -62,7 +62,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
                      const float* __restrict__ cop, float2* __restrict__ partial,
                      const PairHeader* __restrict__ hdr, float cond_limit, int use_if_above,
                      int64_t nblk, int64_t blk_per_split, int64_t cpad, int64_t excl_offset,
-                     PermArgs pa, const int* __restrict__ redo_flags) {
+                     PermArgs pa, const int* __restrict__ redo_flags, int sym) {
     static_assert(!PERM || (NCB == 1 && (EPI == 1 || EPI == 2)), "PERM needs NCB == 1 and a polynomial epilogue");
     // Path gate: the conditioning estimate written by prep decides between this kernel and the direct
     // one without a host round trip (both are launched; the unselected one exits here).
@@ -96,18 +96,36 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
 
     float m[NCB], s[NCB];
     double ks[NCB];       // EPI 1: float64 column sums
-    float kt[NCB];        // EPI 1: float32 sum of the tile in flight
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         m[cb] = LSE_MINIT;
         s[cb] = 0.f;
         ks[cb] = 0.0;
-        kt[cb] = 0.f;
     }
 
-    const int64_t b0 = (int64_t)blockIdx.y * blk_per_split;
+    int64_t b0 = (int64_t)blockIdx.y * blk_per_split;
     int64_t b1 = b0 + blk_per_split;
     if (b1 > nblk) b1 = nblk;
+    // sym (kernel sums of a sample against itself, totals only): the matrix is symmetric, so a column
+    // block only visits the row blocks from its own diagonal tile on (weight 1) and counts the tiles
+    // beyond it twice; the workgroup starts at its first column block's diagonal tile.
+    const bool use_sym = EPI >= 1 && EPI <= 3 && sym != 0;
+    if (use_sym) {
+        const int64_t gs = (int64_t)blockIdx.x * 4 * NCB;
+        if (b0 < gs) b0 = gs;
+    }
+    float wgt[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) wgt[cb] = 1.f;
+    auto set_weights = [&](int64_t pblk) {
+        if (use_sym) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const int64_t cbi = col0 / 32 + cb;
+                wgt[cb] = pblk > cbi ? 2.f : (pblk == cbi ? 1.f : 0.f);
+            }
+        }
+    };
 
     // ---- streaming of the reduced-axis operand through LDS -------------------------------------
     // The four waves of a workgroup sweep the same reduced-axis blocks (each for its own columns), so
@@ -189,8 +207,9 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     // each one issues in the shadow of one MFMA of the NEXT block (64 cycles of matrix-pipe time):
     //   0..7: two exponentials each (packed subtract / add), summed into the tile sum
     //   8: tile sum -> running sum, or the rare redo against a new maximum.
-    // (EPI 1: 17 micro-slices: one pair each, the last one folds the tile sum into float64.)
-    constexpr int EPI_MS = EPI == 4 ? 8 : (EPI >= 1 ? 17 : 9);
+    // (EPI 1-3: eight slices of two kernel values each, the ninth folds the tile sum into float64;
+    //  EPI 4: eight slices of two exponentials, nothing else.)
+    constexpr int EPI_MS = EPI == 4 ? 8 : 9;
     f32x2 m2[NCB], kt2[NCB];            // EPI 0: minus the running max, twice (packed operand); tile sum in flight
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
@@ -213,21 +232,27 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
 #pragma unroll
         for (int k = 0; k < KC; ++k) kc[k] = kp->c[k];
     }
-    auto kfun = [&](float d2) -> float {
-        const float v = fabsf(d2) + k_eps;
-        if (EPI == 1) {
-            return fmaf(kc[1], lvae_exp2(v * k_nbase), kc[0]);
-        } else if (EPI == 2) {
-            const float t = lvae_exp2(v * k_nbase);
-            float pacc = kc[16];
+    // two kernel values at a time (packed fp32 for the polynomial)
+    auto kfun2 = [&](float d2a, float d2b) -> f32x2 {
+        const f32x2 v = {fabsf(d2a) + k_eps, fabsf(d2b) + k_eps};
+        if (EPI == 1 || EPI == 2) {
+            const f32x2 a = v * (f32x2){k_nbase, k_nbase};
+            f32x2 t;
+            t.x = lvae_exp2(a.x);
+            t.y = lvae_exp2(a.y);
+            if (EPI == 1) return __builtin_elementwise_fma((f32x2){kc[1], kc[1]}, t, (f32x2){kc[0], kc[0]});
+            f32x2 pacc = {kc[16], kc[16]};
 #pragma unroll
-            for (int k = 15; k >= 0; --k) pacc = fmaf(pacc, t, kc[k]);
+            for (int k = 15; k >= 0; --k) pacc = __builtin_elementwise_fma(pacc, t, (f32x2){kc[k], kc[k]});
             return pacc;
         } else {
-            float f = 0.f;
+            f32x2 f = {0.f, 0.f};
 #pragma unroll 4
             for (int k = 0; k < KC; ++k)
-                if (k < k_n) f += lvae_exp2(v * kc[k]);
+                if (k < k_n) {
+                    f.x += lvae_exp2(v.x * kc[k]);
+                    f.y += lvae_exp2(v.y * kc[k]);
+                }
             return f;
         }
     };
@@ -236,17 +261,25 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
             // fixed reference (folded into the row biases by lse_shift_bias_kernel): every term is at
             // most 2^LSE_HEADROOM, so the tile is two exponentials and one packed add per slice
             f32x2 e;
+#ifdef LVAE_DBG_NOEXP
+            e.x = prev[cb][2 * ms];
+            e.y = prev[cb][2 * ms + 1];
+#else
             e.x = lvae_exp2(prev[cb][2 * ms]);
             e.y = lvae_exp2(prev[cb][2 * ms + 1]);
+#endif
             kt2[cb] += e;
         } else if (EPI >= 1) {
-            if (ms < 16) {
-                const float kval = kfun(prev[cb][ms]);
-                kt[cb] += kval;
-                if (PERM) kv[ms] = kval;
+            if (ms < 8) {
+                const f32x2 kval = kfun2(prev[cb][2 * ms], prev[cb][2 * ms + 1]);
+                if (ms == 0) kt2[cb] = kval;
+                else kt2[cb] += kval;
+                if (PERM) {
+                    kv[2 * ms] = kval.x;
+                    kv[2 * ms + 1] = kval.y;
+                }
             } else {
-                ks[cb] += (double)kt[cb];
-                kt[cb] = 0.f;
+                ks[cb] += (double)((kt2[cb].x + kt2[cb].y) * wgt[cb]);
             }
         } else if (ms < 8) {
             // two pairs per slice on the packed fp32 pipe: subtract the running max, exponentiate,
@@ -381,6 +414,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     int64_t t_lin = 0;                                     // chunks consumed so far by this wave
     auto run_block = [&](f32x16 (&acc)[NCB], const f32x16 (&prev)[NCB], int64_t blk, bool with_epi) {
         const f32x16 cv = c_pre;
+        if (EPI >= 1 && EPI <= 3) set_weights(blk - 1);
 #pragma unroll
         for (int ch = 0; ch < CPB; ++ch) {
             const int stage = (int)(t_lin % NST);
@@ -392,6 +426,10 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
             a4[0] = a_pre;
 #pragma unroll
             for (int q = 0; q < CQ; ++q) {
+                // The piece read one group ago has had four MFMAs to land: wait for it BEFORE issuing the
+                // next read, otherwise the compiler's own lgkmcnt(0) lands after the new read and stalls
+                // the wave for a full LDS round trip.  (0xC07F = lgkmcnt(0), vmcnt/expcnt untouched.)
+                __builtin_amdgcn_s_waitcnt(0xC07F);
                 if (q + 1 < CQ) {
                     a4[(q + 1) & 1] = read_piece(stage, q + 1);
                 } else {
@@ -429,7 +467,9 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
                 for (int k = 3; k <= PF; ++k) left += per_chunk + (((ch + k) % CPB) == 0 ? (PERM ? 3 : 1) : 0);
                 wait_vmcnt(left);
             }
+#ifndef LVAE_DBG_NOBAR
             __builtin_amdgcn_s_barrier();
+#endif
             ++t_lin;
         }
         if (EXCL) mask_diag(acc, blk);
@@ -456,8 +496,10 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
             run_block(accB, accA, blk, true);
             run_block(accA, accB, blk + 1, true);
         }
+        if (EPI >= 1 && EPI <= 3) set_weights(b1 - 1);
         if (blk < b1) {
             run_block(accB, accA, blk, true);
+            set_weights(b1 - 1);
             drain(accB);
         } else {
             drain(accA);
@@ -505,13 +547,13 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
 template <int DP, int NCB, int WPS>
 static int launch_t(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                     float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
-                    bool excl, int64_t excl_offset, int epi, const int* redo_flags, hipStream_t st) {
+                    bool excl, int64_t excl_offset, int epi, const int* redo_flags, int sym, hipStream_t st) {
     const dim3 grid((unsigned)(p.cpad / (4 * 32 * NCB)), (unsigned)p.nsplit);
     const PermArgs pa{};
 #define LVAE_PAIR(X, E)                                                                              \
     hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, NCB, WPS, X, E>), grid, dim3(256), 0, st, rfrag, rbias, \
                        cop, partial, hdr, cond_limit, use_if_above, p.nblk, p.blk_per_split, p.cpad,  \
-                       excl_offset, pa, redo_flags)
+                       excl_offset, pa, redo_flags, sym)
     switch (epi * 2 + (excl ? 1 : 0)) {
         case 0: LVAE_PAIR(false, 0); break;
         case 1: LVAE_PAIR(true, 0); break;
@@ -535,17 +577,19 @@ static int launch_t(const PairPlan& p, const float* rfrag, const float* rbias, c
 // the row biases; 1/2/3: kernel-matrix column sums (float64 partials; parameters in hdr->ksum: single
 // bandwidth / polynomial of degree <= 16 / arbitrary bandwidths).
 // redo_flags (may be NULL): one int per workgroup column group; workgroups whose flag is 0 exit.
+// sym != 0 (epi 1/2/3 only, kept and reduced operands built from the same sample): visit the upper
+// triangle of tiles only; the TOTAL over columns is that of the full matrix, the per-column sums are not.
 int lvae_launch_pair_mfma(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                           float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
-                          bool excl, int64_t excl_offset, int epi, const int* redo_flags, hipStream_t st) {
+                          bool excl, int64_t excl_offset, int epi, const int* redo_flags, int sym, hipStream_t st) {
     if (p.cpad % (4 * 32 * p.NCB) != 0)
         return lvae_set_error(LVAE_ERR_INVALID, "pair plan: cpad %lld not a multiple of the tile",
                               (long long)p.cpad);
     switch (p.DP) {
-        case 16: return launch_t<16, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, st);
-        case 32: return launch_t<32, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, st);
-        case 64: return launch_t<64, 1, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, st);
-        case 128: return launch_t<128, 1, 1>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, st);
+        case 16: return launch_t<16, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, st);
+        case 32: return launch_t<32, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, st);
+        case 64: return launch_t<64, 1, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, st);
+        case 128: return launch_t<128, 1, 1>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, st);
         default:
             return lvae_set_error(LVAE_ERR_UNSUPPORTED, "MFMA path needs D <= 128 (got D=%d)", p.D);
     }
@@ -556,7 +600,7 @@ int lvae_launch_pair_lse_mfma(const PairPlan& p, const float* rfrag, const float
                               float cond_limit, int use_if_above, bool excl, int64_t excl_offset,
                               hipStream_t st) {
     return lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl,
-                                 excl_offset, 0, nullptr, st);
+                                 excl_offset, 0, nullptr, 0, st);
 }
 
 // Kernel-matrix column sums plus label-permutation sums (see PERM above); diagonal pairs (reduced row ==
@@ -568,10 +612,10 @@ static int launch_perm_t(const PairPlan& p, const float* rfrag, const float* rbi
     const dim3 grid((unsigned)(p.cpad / (4 * 32)), (unsigned)p.nsplit);
     if (epi == 1)
         hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 1, true>), grid, dim3(256), 0, st, rfrag, rbias,
-                           cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr);
+                           cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr, 0);
     else
         hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 2, true>), grid, dim3(256), 0, st, rfrag, rbias,
-                           cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr);
+                           cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr, 0);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }

@@ -60,7 +60,10 @@ struct PairPlan {
 
 static inline size_t lvae_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool with_pm, int force_ncb = 0) {
+// sym: the MFMA grid only does work on the upper triangle of tiles, uneven per workgroup -> cut the reduced
+// axis finer so that the hardware dispatcher can balance it.
+static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool with_pm, int force_ncb = 0,
+                                           bool sym = false) {
     PairPlan p{};
     p.R = R; p.C = C; p.D = D; p.with_pm = with_pm;
     p.DP = lvae_pad_dim(D);
@@ -72,7 +75,7 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
     // MFMA grid: aim at two waves per SIMD on 256 CUs (2048 waves), never more splits than blocks
     const int64_t col_waves = p.DP ? p.cpad / (32 * p.NCB) : 1;
     const char* tw_env = getenv("LVAE_TARGET_WAVES");
-    const int64_t target_waves = tw_env ? atoll(tw_env) : 2048;
+    const int64_t target_waves = (tw_env ? atoll(tw_env) : 2048) * (sym ? 8 : 1);
     int64_t ns = lvae_ceil_div(target_waves, col_waves);
     if (ns > p.nblk) ns = p.nblk;
     if (ns < 1) ns = 1;
