@@ -190,11 +190,15 @@ int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, int64_t nb, 
  * Summed over all owners: k11 = q_p, k12 = lr_p - q_p, k22 = T - 2 lr_p + q_p and
  * statistic_p = k11/(n1(n1-1)) + k22/(n2(n2-1)) - 2 k12/(n1 n2).  The kernel values enter the label
  * contraction as two bf16 limbs (relative error <= 2^-17 per entry, unbiased); bandwidths must be integer
- * multiples (<= 16) of the smallest positive one. */
+ * multiples (<= 16) of the smallest positive one.
+ * symmetric != 0 (needs col_offset % 32 == 0): only the tiles on and above the diagonal of the pooled matrix
+ * are evaluated for the owned columns (about half the work for col_offset = 0, nc = n); the three outputs then
+ * hold this call's share of the same totals -- they still add up over owners to L^T K L, L^T K 1 and 1^T K 1
+ * -- but owners of low columns do more work than owners of high ones. */
 int lvae_mmd_perm_workspace_bytes(int64_t nc, int64_t n, int D, int64_t* out_bytes);
 int lvae_mmd_perm_f32(const float* cols, int64_t nc, int64_t col_offset, const float* pooled, int64_t n, int D,
                       const unsigned char* labels, int P, const float* alphas, int n_alpha, float dist_eps,
-                      double* out, void* ws, int64_t ws_bytes, void* stream);
+                      int symmetric, double* out, void* ws, int64_t ws_bytes, void* stream);
 
 /* The kernel matrix itself (gaussian_kernel, loss_and_optimisation.py:63-76; MMDStatistic ret_matrix):
  * out[i, j] = k(x_i, y_j), out [n1, n2]; alphas on the HOST as above.  Workspace: LVAE_KMAT_WS_BYTES. */

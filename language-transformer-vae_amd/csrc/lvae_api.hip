@@ -64,11 +64,11 @@ int lvae_launch_ksum_columns(const double* partial, int nsplit, int64_t cpad, in
                              hipStream_t st);
 int lvae_launch_pair_mfma_perm(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                                float2* partial, const PairHeader* hdr, int64_t excl_offset, int epi,
-                               const PermArgs& pa, hipStream_t st);
+                               const PermArgs& pa, int sym, hipStream_t st);
 int lvae_launch_prep_labels(const unsigned char* labels, int P, int64_t n, int64_t nblk, void* out,
                             hipStream_t st);
-int lvae_launch_perm_lr(const double* partial, int nsplit, int64_t cpad, int64_t C,
-                        const unsigned char* labels, int64_t n, int64_t col_offset, int P,
+int lvae_launch_perm_lr(const double* partial, const double* diag_partial, int nsplit, int64_t cpad, int64_t C,
+                        const unsigned char* labels, int64_t n, int64_t col_offset, int P, int sym,
                         const double* qperm, double* out, hipStream_t st);
 int lvae_launch_mmd_stat(const double* sums, int64_t n1, int64_t n2, int unbiased, int zero_alphas,
                          double* out, hipStream_t st);
@@ -644,42 +644,49 @@ extern "C" int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, i
 }
 
 // ---- MMD permutation test ------------------------------------------------------------------------------
+// workspace: pair plan | label fragments | diagonal-tile column sums [nsplit][cpad] | 256 float64
 static size_t perm_labfrag_bytes(const PairPlan& p) { return lvae_align256((size_t)p.nblk * 512 * 16); }
+static size_t perm_diag_bytes(const PairPlan& p) { return lvae_align256((size_t)p.nsplit * p.cpad * sizeof(double)); }
 
 extern "C" int lvae_mmd_perm_workspace_bytes(int64_t nc, int64_t n, int D, int64_t* out_bytes) {
     LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
     LVAE_CHECK_ARG(nc >= 1 && n >= 2 && D >= 1, "need nc >= 1, n >= 2, D >= 1");
-    const PairPlan p = lvae_make_pair_plan(n, nc, D, false, 1);
-    *out_bytes = (int64_t)(p.total + perm_labfrag_bytes(p) + 128 * sizeof(double));
+    const PairPlan p = lvae_make_pair_plan(n, nc, D, false, 1, true);
+    *out_bytes = (int64_t)(p.total + perm_labfrag_bytes(p) + perm_diag_bytes(p) + 256 * sizeof(double));
     return LVAE_OK;
 }
 
 extern "C" int lvae_mmd_perm_f32(const float* cols, int64_t nc, int64_t col_offset, const float* pooled,
                                  int64_t n, int D, const unsigned char* labels, int P, const float* alphas,
-                                 int n_alpha, float dist_eps, double* out, void* ws, int64_t ws_bytes,
-                                 void* stream) {
+                                 int n_alpha, float dist_eps, int symmetric, double* out, void* ws,
+                                 int64_t ws_bytes, void* stream) {
     LVAE_CHECK_ARG(cols && pooled && labels && out, "cols, pooled, labels and out must be non-NULL");
     LVAE_CHECK_ARG(n >= 2 && nc >= 1 && col_offset >= 0 && col_offset + nc <= n,
                    "need n >= 2 and 0 <= col_offset, col_offset + nc <= n");
     LVAE_CHECK_ARG(D >= 1 && D <= 128, "the MMD path needs 1 <= D <= 128 (got %d)", D);
     LVAE_CHECK_ARG(n < (1LL << 31), "n must be below 2^31");
     LVAE_CHECK_ARG(P >= 1 && P <= 128, "need 1 <= P <= 128 labelings per call (got %d)", P);
+    LVAE_CHECK_ARG(!symmetric || col_offset % 32 == 0, "symmetric evaluation needs col_offset %% 32 == 0");
     KsumParams kp;
     int zeros = 0;
     int rc = build_ksum(alphas, n_alpha, dist_eps, &kp, &zeros);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const PairPlan p = lvae_make_pair_plan(n, nc, D, false, 1);
+    const int sym = symmetric != 0;
+    const PairPlan p = lvae_make_pair_plan(n, nc, D, false, 1, sym);
+    const PairPlan pmax = lvae_make_pair_plan(n, nc, D, false, 1, true);
     const size_t lab_bytes = perm_labfrag_bytes(p);
-    rc = check_ws(ws, ws_bytes, p.total + lab_bytes + 128 * sizeof(double));
+    const size_t diag_bytes = perm_diag_bytes(p);
+    rc = check_ws(ws, ws_bytes, pmax.total + perm_labfrag_bytes(pmax) + perm_diag_bytes(pmax) + 256 * sizeof(double));
     if (rc) return rc;
     char* base = (char*)ws;
     PairHeader* hdr = (PairHeader*)(base + p.off_hdr);
     float2* partial = (float2*)(base + p.off_partial);
     void* labfrag = base + p.total;
-    double* qperm = (double*)(base + p.total + lab_bytes);
+    double* diag_partial = (double*)(base + p.total + lab_bytes);
+    double* qperm = (double*)(base + p.total + lab_bytes + diag_bytes);
     LVAE_HIP(hipMemsetAsync(hdr, 0, sizeof(PairHeader), st));
-    LVAE_HIP(hipMemsetAsync(qperm, 0, 128 * sizeof(double), st));
+    LVAE_HIP(hipMemsetAsync(qperm, 0, 256 * sizeof(double), st));
     rc = lvae_launch_set_ksum(hdr, kp, st);
     if (rc) return rc;
     if (kp.n == 0 && kp.c[0] == 0.f) {      // only alpha = 0 bandwidths: the statistic is identically 0
@@ -698,15 +705,17 @@ extern "C" int lvae_mmd_perm_f32(const float* cols, int64_t nc, int64_t col_offs
     pa.labfrag = labfrag;
     pa.labels = labels;
     pa.qperm = qperm;
+    pa.diag_partial = diag_partial;
     pa.n_lab = n;
     pa.col_offset = col_offset;
     pa.C = nc;
     pa.P = P;
     rc = lvae_launch_pair_mfma_perm(p, (float*)(base + p.off_rfrag), (float*)(base + p.off_rbias),
-                                    (float*)(base + p.off_cop), partial, hdr, col_offset, ksum_epi(kp), pa, st);
+                                    (float*)(base + p.off_cop), partial, hdr, col_offset, ksum_epi(kp), pa, sym,
+                                    st);
     if (rc) return rc;
-    return lvae_launch_perm_lr((const double*)partial, p.nsplit, p.cpad, nc, labels, n, col_offset, P, qperm,
-                               out, st);
+    return lvae_launch_perm_lr((const double*)partial, diag_partial, p.nsplit, p.cpad, nc, labels, n, col_offset,
+                               P, sym, qperm, out, st);
 }
 
 extern "C" int lvae_kernel_matrix_f32(const float* x, const float* y, int64_t n1, int64_t n2, int D,

@@ -277,22 +277,28 @@ __global__ void __launch_bounds__(256) prep_labels_kernel(const unsigned char* _
     out[idx] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// Block p < P: lr_p = sum_i label[p][col_offset + i] * r_i with r_i = sum_k partial[k][i] (the kernel
-// sums of kept element i over the whole pooled sample); block P: T = sum_i r_i.
+// Block p < P: lr_p = sum_i label[p][col_offset + i] * cs_i (+ ysum_p when sym); block P: T.
+// cs_i = sum_k partial[k][i]: the kernel sums of kept element i over the visited rows -- all of the pooled
+// sample, or with sym the rows beyond its diagonal tile, whose own sums are in diag_partial; then the
+// missing half of lr_p is ysum_p = sum_c (K L_p)[c] over the visited tiles and T = 2 sum cs + sum diag.
 // out = [q_0..q_{P-1}, lr_0..lr_{P-1}, T].
-__global__ void __launch_bounds__(256) perm_lr_kernel(const double* __restrict__ partial, int nsplit,
+__global__ void __launch_bounds__(256) perm_lr_kernel(const double* __restrict__ partial,
+                                                      const double* __restrict__ diag_partial, int nsplit,
                                                       int64_t cpad, int64_t C,
                                                       const unsigned char* __restrict__ labels, int64_t n,
-                                                      int64_t col_offset, int P,
+                                                      int64_t col_offset, int P, int sym,
                                                       const double* __restrict__ qperm,
                                                       double* __restrict__ out) {
     const int p = blockIdx.x;
     double acc = 0.0;
     for (int64_t i = threadIdx.x; i < C; i += 256) {
         if (p == P || labels[(int64_t)p * n + col_offset + i]) {
-            double r = 0.0;
-            for (int k = 0; k < nsplit; ++k) r += partial[k * cpad + i];
-            acc += r;
+            double cs = 0.0, dg = 0.0;
+            for (int k = 0; k < nsplit; ++k) {
+                cs += partial[k * cpad + i];
+                if (sym) dg += diag_partial[k * cpad + i];
+            }
+            acc += (p == P && sym) ? 2.0 * cs + dg : cs;
         }
     }
     acc = wave_sum_d(acc);
@@ -303,7 +309,7 @@ __global__ void __launch_bounds__(256) perm_lr_kernel(const double* __restrict__
         const double tot = sm[0] + sm[1] + sm[2] + sm[3];
         if (p == P) out[2 * P] = tot;
         else {
-            out[P + p] = tot;
+            out[P + p] = tot + (sym ? qperm[128 + p] : 0.0);
             out[p] = qperm[p];
         }
     }
@@ -318,11 +324,11 @@ int lvae_launch_prep_labels(const unsigned char* labels, int P, int64_t n, int64
     return LVAE_OK;
 }
 
-int lvae_launch_perm_lr(const double* partial, int nsplit, int64_t cpad, int64_t C,
-                        const unsigned char* labels, int64_t n, int64_t col_offset, int P,
+int lvae_launch_perm_lr(const double* partial, const double* diag_partial, int nsplit, int64_t cpad, int64_t C,
+                        const unsigned char* labels, int64_t n, int64_t col_offset, int P, int sym,
                         const double* qperm, double* out, hipStream_t st) {
-    hipLaunchKernelGGL(perm_lr_kernel, dim3((unsigned)(P + 1)), dim3(256), 0, st, partial, nsplit, cpad, C,
-                       labels, n, col_offset, P, qperm, out);
+    hipLaunchKernelGGL(perm_lr_kernel, dim3((unsigned)(P + 1)), dim3(256), 0, st, partial, diag_partial, nsplit,
+                       cpad, C, labels, n, col_offset, P, sym, qperm, out);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }

@@ -96,6 +96,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
 
     float m[NCB], s[NCB];
     double ks[NCB];       // EPI 1: float64 column sums
+    double ksd = 0.0;     // PERM + sym: column sums of the diagonal tile
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         m[cb] = LSE_MINIT;
@@ -110,8 +111,9 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     // block only visits the row blocks from its own diagonal tile on (weight 1) and counts the tiles
     // beyond it twice; the workgroup starts at its first column block's diagonal tile.
     const bool use_sym = EPI >= 1 && EPI <= 3 && sym != 0;
+    const int64_t sym_off = PERM ? pa.col_offset / 32 : 0;    // block index of kept element 0 on the reduced axis
     if (use_sym) {
-        const int64_t gs = (int64_t)blockIdx.x * 4 * NCB;
+        const int64_t gs = sym_off + (int64_t)blockIdx.x * 4 * NCB;
         if (b0 < gs) b0 = gs;
     }
     float wgt[NCB];
@@ -121,7 +123,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
         if (use_sym) {
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
-                const int64_t cbi = col0 / 32 + cb;
+                const int64_t cbi = sym_off + col0 / 32 + cb;
                 wgt[cb] = pblk > cbi ? 2.f : (pblk == cbi ? 1.f : 0.f);
             }
         }
@@ -278,6 +280,11 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
                     kv[2 * ms] = kval.x;
                     kv[2 * ms + 1] = kval.y;
                 }
+            } else if (PERM) {
+                // strictly-upper (or, without sym, all) tiles and the diagonal tile are kept apart
+                const float ts = kt2[cb].x + kt2[cb].y;
+                if (use_sym && wgt[cb] == 1.f) ksd += (double)ts;
+                else if (!use_sym || wgt[cb] == 2.f) ks[cb] += (double)ts;
             } else {
                 ks[cb] += (double)((kt2[cb].x + kt2[cb].y) * wgt[cb]);
             }
@@ -327,9 +334,14 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     f32x16 Y[PERM ? 4 : 1];
     double qacc[PERM ? 4 : 1];
+    double yacc[PERM ? 4 : 1];          // unweighted sums of Y (sym: one half of lr_p)
     unsigned cmask[PERM ? 4 : 1];       // bit e: label of kept element (accumulator row e) under labeling 32*pt + r
+    unsigned vmask = 0;                 // bit e: accumulator row e is a real kept element (not padding)
     int pcount = 0;
     if (PERM) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (col0 + (e & 3) + 8 * (e >> 2) + 4 * h < pa.C) vmask |= 1u << e;
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
             unsigned mk = 0;
@@ -341,24 +353,30 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
             }
             cmask[pt] = mk;
             qacc[pt] = 0.0;
+            yacc[pt] = 0.0;
 #pragma unroll
             for (int e = 0; e < 16; ++e) Y[pt][e] = 0.f;
         }
     }
-    auto perm_flush = [&]() __attribute__((always_inline)) {
+    auto perm_flush = [&](float wv) __attribute__((always_inline)) {
 #pragma unroll
         for (int pt = 0; pt < (PERM ? 4 : 0); ++pt) {
-            float t = 0.f;
+            float t = 0.f, u = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 t += ((cmask[pt] >> e) & 1u) ? Y[pt][e] : 0.f;
+                u += ((vmask >> e) & 1u) ? Y[pt][e] : 0.f;
                 Y[pt][e] = 0.f;
             }
-            qacc[pt] += (double)t;
+            qacc[pt] += (double)(t * wv);
+            yacc[pt] += (double)u;
         }
     };
     // kv (the finished tile, accumulator layout: lane = column, 16 rows) -> two bf16 limbs -> 16 MFMAs
-    auto perm_tile = [&](int lstage) __attribute__((always_inline)) {
+    // wv: weight of the tile (sym: 0 below the diagonal tile -> nothing to do, 1 on it, 2 beyond; else 1).
+    // A flush never mixes weights: the diagonal tile is flushed on its own.
+    auto perm_tile = [&](int lstage, float wv) __attribute__((always_inline)) {
+        if (wv == 0.f) return;
         bf16x8 ahi[2], alo[2];
 #pragma unroll
         for (int sp = 0; sp < 2; ++sp)
@@ -382,8 +400,8 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
                 Y[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[sp], b, Y[pt], 0, 0, 0);
                 Y[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[sp], b, Y[pt], 0, 0, 0);
             }
-        if (++pcount == PERM_FLUSH) {
-            perm_flush();
+        if ((use_sym && wv == 1.f) || ++pcount == PERM_FLUSH) {
+            perm_flush(wv);
             pcount = 0;
         }
     };
@@ -456,7 +474,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
                     }
                 }
             }
-            if (PERM && with_epi && ch == CPB - 1) perm_tile((int)((blk - 1 - b0) % NSTL));
+            if (PERM && with_epi && ch == CPB - 1) perm_tile((int)((blk - 1 - b0) % NSTL), wgt[0]);
             // my pieces of chunk t_lin+2 have landed; after the barrier everybody's have, and
             // everybody is done reading chunk t_lin's stage
             // (chunks t_lin+3 .. t_lin+PF, issued later, may stay in flight: counted wait)
@@ -505,12 +523,16 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
             drain(accA);
         }
         if (PERM) {
-            perm_tile((int)((b1 - 1 - b0) % NSTL));
-            if (pcount) perm_flush();
+            perm_tile((int)((b1 - 1 - b0) % NSTL), wgt[0]);
+            if (pcount) perm_flush(wgt[0]);
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) {
                 const double tot = qacc[pt] + __shfl_xor(qacc[pt], 32, 64);
-                if (h == 0 && 32 * pt + r < pa.P) atomicAdd(&pa.qperm[32 * pt + r], tot);
+                const double ytot = yacc[pt] + __shfl_xor(yacc[pt], 32, 64);
+                if (h == 0 && 32 * pt + r < pa.P) {
+                    atomicAdd(&pa.qperm[32 * pt + r], tot);
+                    if (use_sym) atomicAdd(&pa.qperm[128 + 32 * pt + r], ytot);
+                }
             }
         }
     }
@@ -531,6 +553,10 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
         for (int cb = 0; cb < NCB; ++cb) {
             const double tot = ks[cb] + __shfl_xor(ks[cb], 32, 64);
             if (h == 0) kpartial[(int64_t)blockIdx.y * cpad + col0 + cb * 32 + r] = tot;
+        }
+        if (PERM) {
+            const double dtot = ksd + __shfl_xor(ksd, 32, 64);
+            if (h == 0) pa.diag_partial[(int64_t)blockIdx.y * cpad + col0 + r] = dtot;
         }
         return;
     }
@@ -608,21 +634,23 @@ int lvae_launch_pair_lse_mfma(const PairPlan& p, const float* rfrag, const float
 template <int DP, int WPS>
 static int launch_perm_t(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                          float2* partial, const PairHeader* hdr, int64_t excl_offset, int epi,
-                         const PermArgs& pa, hipStream_t st) {
+                         const PermArgs& pa, int sym, hipStream_t st) {
     const dim3 grid((unsigned)(p.cpad / (4 * 32)), (unsigned)p.nsplit);
     if (epi == 1)
         hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 1, true>), grid, dim3(256), 0, st, rfrag, rbias,
-                           cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr, 0);
+                           cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr, sym);
     else
         hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 2, true>), grid, dim3(256), 0, st, rfrag, rbias,
-                           cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr, 0);
+                           cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr, sym);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }
 
 int lvae_launch_pair_mfma_perm(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                                float2* partial, const PairHeader* hdr, int64_t excl_offset, int epi,
-                               const PermArgs& pa, hipStream_t st) {
+                               const PermArgs& pa, int sym, hipStream_t st) {
+    if (sym && pa.col_offset % 32 != 0)
+        return lvae_set_error(LVAE_ERR_INVALID, "symmetric permutation sums need col_offset %% 32 == 0");
     if (p.NCB != 1 || p.cpad % 128 != 0)
         return lvae_set_error(LVAE_ERR_INVALID, "permutation plan needs NCB == 1 and cpad %% 128 == 0");
     if (epi != 1 && epi != 2)
@@ -631,10 +659,10 @@ int lvae_launch_pair_mfma_perm(const PairPlan& p, const float* rfrag, const floa
                               "smallest one");
     if (pa.P < 1 || pa.P > 128) return lvae_set_error(LVAE_ERR_INVALID, "need 1 <= labelings <= 128 per pass");
     switch (p.DP) {
-        case 16: return launch_perm_t<16, 2>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, st);
-        case 32: return launch_perm_t<32, 2>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, st);
-        case 64: return launch_perm_t<64, 1>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, st);
-        case 128: return launch_perm_t<128, 1>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, st);
+        case 16: return launch_perm_t<16, 2>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, st);
+        case 32: return launch_perm_t<32, 2>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, st);
+        case 64: return launch_perm_t<64, 1>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, st);
+        case 128: return launch_perm_t<128, 1>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, st);
         default:
             return lvae_set_error(LVAE_ERR_UNSUPPORTED, "MFMA path needs D <= 128 (got D=%d)", p.D);
     }

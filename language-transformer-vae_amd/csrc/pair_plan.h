@@ -34,7 +34,8 @@ struct PairHeader {
 struct PermArgs {
     const void* labfrag;             // [nblk][4 perm tiles][2 steps][64 lanes][8 bf16] (prep_labels_kernel)
     const unsigned char* labels;     // [P][n_lab] 0/1, for the kept-axis side
-    double* qperm;                   // [128]
+    double* qperm;                   // [256]: q_p partial sums, then (sym) the unweighted sums of Y
+    double* diag_partial;            // [nsplit][cpad]: column sums of the diagonal tiles (sym)
     int64_t n_lab;                   // pooled sample size (row stride of labels)
     int64_t col_offset;              // pooled index of kept element 0
     int64_t C;                       // kept elements

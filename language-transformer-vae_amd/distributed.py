@@ -176,31 +176,45 @@ def sharded_mmd(x_local, y_local, alphas, dist_eps=0.0, unbiased=False, group=No
             "sum_kxy": sxy, "n1": int(n1), "n2": int(n2)}
 
 
-def hip_permutation_sums(cols, col_offset, pooled, labels, alphas, dist_eps):
+def hip_permutation_sums(cols, col_offset, pooled, labels, alphas, dist_eps, symmetric):
     from . import estimators as E
-    return E.mmd_permutation_sums(cols, col_offset, pooled, labels, alphas, dist_eps)
+    return E.mmd_permutation_sums(cols, col_offset, pooled, labels, alphas, dist_eps, symmetric)
+
+
+def mirrored_chunks(n, world_size, rank, align=32):
+    """Column ranges of the pooled sample for one rank when only the upper triangle of the kernel matrix is
+    evaluated: the columns are cut into 2*world_size chunks (multiples of ``align``) and rank r takes chunks
+    r and 2*world_size-1-r, whose work (rows beyond the column) adds up to the same for every rank."""
+    nchunks = 2 * world_size
+    cs = -(-n // nchunks)
+    cs = -(-cs // align) * align
+    out = []
+    for k in (rank, nchunks - 1 - rank):
+        lo, hi = min(k * cs, n), min((k + 1) * cs, n)
+        if hi > lo:
+            out.append((lo, hi))
+    return out
 
 
 def sharded_mmd_permutation_test(x_local, y_local, alphas, labels, dist_eps=1e-5, group=None,
                                  permutation_sums=hip_permutation_sums):
     """MMD permutation test with both samples sharded by rows (samples replicated by
     all-gather, kernel-matrix columns partitioned, all-reduce of the [P, 2] label sums and the total).
+    After the gather every rank holds the pooled sample, so the COMPUTE partition is free: each rank
+    evaluates two mirrored column chunks of the upper triangle (``mirrored_chunks``), half the work of the
+    full matrix and balanced over ranks.
     ``labels``: [P, n1 + n2] uint8, identical on every rank (row 0 = observed labeling: first n1 ones), in
     POOLED order = all of x (rank order) followed by all of y.  Returns a dict identical on every rank."""
-    x_all, xoff = all_gather_rows(x_local.contiguous(), group)
-    y_all, yoff = all_gather_rows(y_local.contiguous(), group)
-    rank = dist.get_rank(group)
+    x_all, _ = all_gather_rows(x_local.contiguous(), group)
+    y_all, _ = all_gather_rows(y_local.contiguous(), group)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
     n1, n2 = x_all.shape[0], y_all.shape[0]
     pooled = torch.cat((x_all, y_all), 0).contiguous()
-    parts = []
-    for cols, off in ((x_local, xoff[rank]), (y_local, n1 + yoff[rank])):
-        if cols.shape[0] == 0:
-            continue
-        q, lr, tot = permutation_sums(cols.contiguous(), off, pooled, labels, alphas, dist_eps)
-        parts.append(torch.cat((q.reshape(-1), lr.reshape(-1), tot.reshape(1))).to(torch.float64))
     P = labels.shape[0]
-    sums = torch.stack(parts).sum(0) if parts else torch.zeros(2 * P + 1, dtype=torch.float64,
-                                                               device=pooled.device)
+    sums = torch.zeros(2 * P + 1, dtype=torch.float64, device=pooled.device)
+    for lo, hi in mirrored_chunks(n1 + n2, world, rank):
+        q, lr, tot = permutation_sums(pooled[lo:hi].contiguous(), lo, pooled, labels, alphas, dist_eps, True)
+        sums += torch.cat((q.reshape(-1), lr.reshape(-1), tot.reshape(1))).to(torch.float64)
     _all_reduce(sums, dist.ReduceOp.SUM, group)
     s = sums.cpu()
     q, lr, tot = s[:P], s[P:2 * P], s[2 * P]

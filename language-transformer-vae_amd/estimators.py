@@ -191,12 +191,16 @@ def kernel_sum(a, b, alphas, dist_eps, exclude_diag=False, diag_offset=0, colsum
     return (total[0], cs) if colsum else total[0]
 
 
-def mmd_permutation_sums(cols, col_offset, pooled, labels, alphas, dist_eps):
+def mmd_permutation_sums(cols, col_offset, pooled, labels, alphas, dist_eps, symmetric=None):
     """Label-permutation sums of the pooled kernel matrix for the columns this caller owns
     (lvae_mmd_perm_f32): returns (q [P], lr [P], T) as float64 device tensors.  ``labels`` is a [P, n]
     uint8 device tensor (non-zero: element belongs to sample 1 under that labeling); any P (the C entry
-    point takes 128 labelings per pass)."""
+    point takes 128 labelings per pass).  ``symmetric`` evaluates only the tiles on and above the
+    diagonal (col_offset must be a multiple of 32); the shares of all owners still add up to the same
+    totals PROVIDED every owner uses the same mode.  Default: symmetric iff the call owns all columns."""
     cols, pooled = N.as_f32(cols, "cols"), N.as_f32(pooled, "pooled")
+    if symmetric is None:
+        symmetric = int(col_offset) == 0 and cols.shape[0] == pooled.shape[0]
     if labels.dtype != torch.uint8 or labels.dim() != 2 or labels.shape[1] != pooled.shape[0]:
         raise ValueError("labels must be a [P, n] uint8 tensor")
     if not labels.is_cuda:
@@ -217,8 +221,8 @@ def mmd_permutation_sums(cols, col_offset, pooled, labels, alphas, dist_eps):
             pp = lab.shape[0]
             out = torch.empty(2 * pp + 1, dtype=torch.float64, device=dev)
             N.check(N.lib().lvae_mmd_perm_f32(N.ptr(cols), nc, int(col_offset), N.ptr(pooled), n, D, N.ptr(lab),
-                                              pp, arr, nalpha, float(dist_eps), N.ptr(out), N.ptr(ws),
-                                              nbytes.value, N.stream_ptr(dev)))
+                                              pp, arr, nalpha, float(dist_eps), int(bool(symmetric)),
+                                              N.ptr(out), N.ptr(ws), nbytes.value, N.stream_ptr(dev)))
             q[p0:p0 + pp] = out[:pp]
             lr[p0:p0 + pp] = out[pp:2 * pp]
             tot = out[2 * pp]

@@ -161,17 +161,31 @@ def test_sharded_mmd_world2():
     assert results[0][1] == results[1][1]
 
 
-def _oracle_permutation_sums(cols, col_offset, pooled, labels, alphas, dist_eps):
+def _oracle_permutation_sums(cols, col_offset, pooled, labels, alphas, dist_eps, symmetric):
+    """This owner's share of (L^T K L, L^T K 1, 1^T K 1); symmetric: from the 32x32 tiles on and above the
+    diagonal only, exactly as include/lvae.h describes for lvae_mmd_perm_f32."""
     c64, p64 = cols.numpy().astype(np.float64), pooled.numpy().astype(np.float64)
+    nc, n = c64.shape[0], p64.shape[0]
     d2 = dist_eps + np.abs((c64 ** 2).sum(1)[:, None] + (p64 ** 2).sum(1)[None] - 2.0 * c64 @ p64.T)
-    K = sum(np.exp(-al * d2) for al in alphas if al > 0)
-    i = np.arange(c64.shape[0])
+    K = sum(np.exp(-al * d2) for al in alphas if al > 0)     # [nc, n]: K[c, r]
+    i = np.arange(nc)
     K[i, i + col_offset] = 0.0
     L = (labels.numpy() != 0).astype(np.float64)            # [P, n]
-    Lc = L[:, col_offset:col_offset + c64.shape[0]]          # [P, nc]
-    q = np.einsum("pc,cr,pr->p", Lc, K, L)
-    r = K.sum(1)
-    return torch.from_numpy(q), torch.from_numpy(Lc @ r), torch.tensor(r.sum())
+    Lc = L[:, col_offset:col_offset + nc]                    # [P, nc]
+    if not symmetric:
+        q = np.einsum("pc,cr,pr->p", Lc, K, L)
+        r = K.sum(1)
+        return torch.from_numpy(q), torch.from_numpy(Lc @ r), torch.tensor(r.sum())
+    assert col_offset % 32 == 0
+    cb = (col_offset + i) // 32
+    rb = np.arange(n) // 32
+    strict = (rb[None, :] > cb[:, None]).astype(np.float64)
+    diag = (rb[None, :] == cb[:, None]).astype(np.float64)
+    Ks, Kd = K * strict, K * diag
+    q = 2.0 * np.einsum("pc,cr,pr->p", Lc, Ks, L) + np.einsum("pc,cr,pr->p", Lc, Kd, L)
+    lr = np.einsum("cr,pr->p", Ks + Kd, L) + Lc @ Ks.sum(1)
+    tot = 2.0 * Ks.sum() + Kd.sum()
+    return torch.from_numpy(q), torch.from_numpy(lr), torch.tensor(tot)
 
 
 def _perm_worker(rank, world, port, n1, n2, D, P, q):
@@ -199,7 +213,7 @@ def _perm_worker(rank, world, port, n1, n2, D, P, q):
 
 def test_sharded_mmd_permutation_world2():
     from oracle import oracle_np as onp
-    n1, n2, D, P, world = 41, 36, 8, 12, 2
+    n1, n2, D, P, world = 141, 136, 8, 12, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

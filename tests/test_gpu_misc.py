@@ -216,15 +216,29 @@ def test_mmd_permutation_test_unpinned(n1, n2, D, P):
     st(dev(a), dev(b), alphas)
     pv = st.pval(None, n_permutations=16)
     assert 0.0 <= pv <= 1.0
-    # column-sharded evaluation adds up to the same sums
+    # column-sharded evaluation adds up to the same sums, with the full rows ...
     pooled = torch.cat((dev(a), dev(b)), 0)
-    q, lr, tot = E.mmd_permutation_sums(pooled, 0, pooled, labels, alphas, 1e-5)
+    q, lr, tot = E.mmd_permutation_sums(pooled, 0, pooled, labels, alphas, 1e-5)         # symmetric
+    qf, lrf, totf = E.mmd_permutation_sums(pooled, 0, pooled, labels, alphas, 1e-5, symmetric=False)
+    np.testing.assert_allclose(qf.cpu().numpy(), q.cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(lrf.cpu().numpy(), lr.cpu().numpy(), rtol=1e-6)
+    assert abs(float(totf) - float(tot)) <= 1e-6 * float(tot)      # K[r][c] and K[c][r] round differently
     cut = (n1 + n2) // 3
     q1, lr1, t1 = E.mmd_permutation_sums(pooled[:cut].contiguous(), 0, pooled, labels, alphas, 1e-5)
     q2, lr2, t2 = E.mmd_permutation_sums(pooled[cut:].contiguous(), cut, pooled, labels, alphas, 1e-5)
     np.testing.assert_allclose((q1 + q2).cpu().numpy(), q.cpu().numpy(), rtol=1e-6)
-    np.testing.assert_allclose((lr1 + lr2).cpu().numpy(), lr.cpu().numpy(), rtol=1e-9)
-    assert abs(float(t1 + t2) - float(tot)) <= 1e-9 * float(tot)
+    np.testing.assert_allclose((lr1 + lr2).cpu().numpy(), lr.cpu().numpy(), rtol=1e-6)
+    assert abs(float(t1 + t2) - float(tot)) <= 1e-6 * float(tot)
+    # ... and with the upper triangle only (32-aligned mirrored chunks, as the sharded test uses them)
+    from lvae.distributed import mirrored_chunks
+    acc = None
+    for rank in range(3):
+        for lo, hi in mirrored_chunks(n1 + n2, 3, rank):
+            part = E.mmd_permutation_sums(pooled[lo:hi].contiguous(), lo, pooled, labels, alphas, 1e-5, True)
+            vec = torch.cat((part[0], part[1], part[2].reshape(1)))
+            acc = vec if acc is None else acc + vec
+    want = torch.cat((q, lr, tot.reshape(1)))
+    np.testing.assert_allclose(acc.cpu().numpy(), want.cpu().numpy(), rtol=1e-6)
 
 
 def test_get_tts_mmmd_and_encode_tail():
