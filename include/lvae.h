@@ -55,6 +55,12 @@ int lvae_version(void);
  * z [M,D]; mu, spread [N,D]; log_qz [M]; log_qz_prod_marg [M] or NULL.
  * ------------------------------------------------------------------------------------------- */
 int lvae_log_qz_workspace_bytes(int64_t M, int64_t N, int D, int with_prod_marg, int64_t* out_bytes);
+
+/* Diagnostic (no counterpart in the reference): the launch plan of lvae_log_qz_f32 for these sizes.
+ * out[8] = {padded latent dim of the MFMA path (0: unsupported), column blocks per wave, padded M, splits of
+ * the posterior axis, 32-row blocks per split, splits of the direct path, 32-row blocks, workspace bytes}.
+ * Host only; used by the tests of the grid quantisation. */
+int lvae_plan_info(int64_t M, int64_t N, int D, int prod_marginals, int64_t* out);
 int lvae_log_qz_f32(const float* z, const float* mu, const float* spread, int spread_kind,
                     int64_t M, int64_t N, int D, float log_norm,
                     int exclude_diag, int64_t diag_offset, int path,

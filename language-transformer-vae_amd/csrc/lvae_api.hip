@@ -290,6 +290,15 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     return LVAE_OK;
 }
 
+extern "C" int lvae_plan_info(int64_t M, int64_t N, int D, int prod_marginals, int64_t* out) {
+    LVAE_CHECK_ARG(out, "out is NULL");
+    LVAE_CHECK_ARG(M >= 1 && N >= 1 && D >= 1, "need M, N, D >= 1");
+    const PairPlan p = lvae_make_pair_plan(N, M, D, prod_marginals != 0);
+    out[0] = p.DP; out[1] = p.NCB; out[2] = p.cpad; out[3] = p.nsplit; out[4] = p.blk_per_split;
+    out[5] = p.dsplit; out[6] = p.nblk; out[7] = (int64_t)p.total;
+    return LVAE_OK;
+}
+
 extern "C" int lvae_log_qz_f32(const float* z, const float* mu, const float* spread, int spread_kind,
                                int64_t M, int64_t N, int D, float log_norm, int exclude_diag,
                                int64_t diag_offset, int path, float* log_qz, float* log_qz_prod_marg,

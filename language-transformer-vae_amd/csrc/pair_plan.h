@@ -73,14 +73,32 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
     p.nblk = lvae_ceil_div(R, 32);
     const int64_t wg_cols = p.DP ? 4 * 32 * p.NCB : 256;
     p.cpad = lvae_round_up(C, wg_cols < 256 ? 256 : wg_cols);
-    // MFMA grid: aim at two waves per SIMD on 256 CUs (2048 waves), never more splits than blocks
-    const int64_t col_waves = p.DP ? p.cpad / (32 * p.NCB) : 1;
-    const char* tw_env = getenv("LVAE_TARGET_WAVES");
-    const int64_t target_waves = (tw_env ? atoll(tw_env) : 2048) * (sym ? 8 : 1);
-    int64_t ns = lvae_ceil_div(target_waves, col_waves);
-    if (ns > p.nblk) ns = p.nblk;
+    // MFMA grid: (column groups) x (reduced-axis splits).  All workgroups of a launch do the same work, S of
+    // them are resident at a time (two per CU, one for the D=128 variant), so the time is
+    // rounds * (blocks per split + per-workgroup overhead) with rounds = ceil(groups * splits / S): pick the
+    // split count that minimises it (a grid of 543 equal workgroups on 512 slots would take two full rounds).
+    // sym: uneven work per workgroup -> at least 8 rounds' worth of workgroups for the dispatcher to balance.
+    const int64_t groups = p.DP ? p.cpad / (4 * 32 * p.NCB) : 1;
+    const char* tw_env = getenv("LVAE_NSPLIT");
+    const int64_t slots = 256 * (p.DP == 128 ? 1 : 2);
+    const int64_t max_ns = p.nblk < 64 ? (p.nblk < 1 ? 1 : p.nblk) : 64;
+    int64_t ns = 1;
+    if (tw_env) {
+        ns = atoll(tw_env);
+    } else {
+        double best = 1e300;
+        for (int64_t c = 1; c <= max_ns; ++c) {
+            if (sym && groups * c < 8 * slots && c < max_ns) continue;
+            const int64_t rounds = lvae_ceil_div(groups * c, slots);
+            const double cost = (double)rounds * ((double)lvae_ceil_div(p.nblk, c) + 4.0);
+            if (cost < best * 0.999) {
+                best = cost;
+                ns = c;
+            }
+        }
+    }
+    if (ns > max_ns) ns = max_ns;
     if (ns < 1) ns = 1;
-    if (ns > 64) ns = 64;
     p.blk_per_split = lvae_ceil_div(p.nblk, ns);
     p.nsplit = (int)lvae_ceil_div(p.nblk, p.blk_per_split);
     // direct grid: one lane per kept element, 64 per wave

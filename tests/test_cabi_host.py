@@ -124,3 +124,22 @@ def test_shard_bounds():
         assert all(spans[i][1] == spans[i + 1][0] for i in range(ws - 1))
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_grid_quantisation_of_multi_gpu_shapes():
+    """Host logic: the split of the posterior axis must not leave a nearly empty last round of workgroups
+    (e.g. 543 equal workgroups on 512 resident slots) for the per-rank shapes of the weak-scaling bench."""
+    import ctypes
+    import math
+    from lvae import _native as N
+    for world in (1, 2, 4, 8):
+        q = 256 * world
+        n = max(q, int(round(65536 * math.sqrt(world) / q)) * q)
+        out = (ctypes.c_int64 * 8)()
+        N.check(N.lib().lvae_plan_info(n // world, n, 32, 0, out))
+        dp, ncb, cpad, nsplit, bps, _, nblk, _ = list(out)
+        assert dp == 32 and nsplit * bps >= nblk
+        groups = cpad // (128 * ncb)
+        rounds = -(-groups * nsplit // 512)
+        eff = (groups * nblk / 512) / (rounds * bps)
+        assert eff > 0.95, (world, groups, nsplit, eff)
