@@ -77,7 +77,7 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
     // them are resident at a time (two per CU, one for the D=128 variant), so the time is
     // rounds * (blocks per split + per-workgroup overhead) with rounds = ceil(groups * splits / S): pick the
     // split count that minimises it (a grid of 543 equal workgroups on 512 slots would take two full rounds).
-    // sym: uneven work per workgroup -> at least 8 rounds' worth of workgroups for the dispatcher to balance.
+    // At least five rounds' worth of workgroups (sym: uneven work per workgroup -> eight) when the axis allows.
     const int64_t groups = p.DP ? p.cpad / (4 * 32 * p.NCB) : 1;
     const char* tw_env = getenv("LVAE_NSPLIT");
     const int64_t slots = 256 * (p.DP == 128 ? 1 : 2);
@@ -88,7 +88,8 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
     } else {
         double best = 1e300;
         for (int64_t c = 1; c <= max_ns; ++c) {
-            if (sym && groups * c < 8 * slots && c < max_ns) continue;
+            // measured at C2: five rounds of smaller workgroups beat one round of large ones by 2.4 %
+            if (groups * c < (sym ? 8 : 5) * slots && c < max_ns) continue;
             const int64_t rounds = lvae_ceil_div(groups * c, slots);
             const double cost = (double)rounds * ((double)lvae_ceil_div(p.nblk, c) + 4.0);
             if (cost < best * 0.999) {
