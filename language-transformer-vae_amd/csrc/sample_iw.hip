@@ -39,7 +39,6 @@ sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
                  float* __restrict__ log_p_z, float* __restrict__ iw_ll) {
     const int64_t b = blockIdx.x;
     const int gl = threadIdx.x % G;          // lane inside the row group: owns dims 4*gl .. 4*gl+3
-    const int grp = threadIdx.x / G;
     const int rows_per_iter = (256 / G) * U;
     const bool have_post = mu != nullptr;
     f32x4 m4 = {0.f, 0.f, 0.f, 0.f}, lv4 = m4, sd4 = m4, iv4 = m4;
@@ -54,15 +53,22 @@ sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
     }
     float lm = -INFINITY, ls = 0.f;
     const float* __restrict__ base = src + b * K * D;
+    // Row of (group g of the wave, load u) = wave base + u * Gw + g: one wave-instruction reads Gw
+    // consecutive rows = 1 KiB of contiguous memory, and the 64 results a wave owns are 64 consecutive
+    // floats (lane u of group g owns row u * Gw + g).
+    const int Gw = 64 / G;                                // row groups per wave
+    const int gw = (threadIdx.x & 63) / G;                // this lane's group inside its wave
+    const int wave_rows = Gw * U;
     for (int64_t k0 = 0; k0 < K; k0 += rows_per_iter) {
-        const int64_t kg = k0 + (int64_t)grp * U;        // first row of this group
+        const int64_t kw = k0 + (int64_t)(threadIdx.x >> 6) * wave_rows + gw;   // row of load 0
         f32x4 v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (kg + u < K) v[u] = *reinterpret_cast<const f32x4*>(base + (kg + u) * D + 4 * gl);
+            if (kw + u * Gw < K)
+                v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (kw + u * Gw) * D + 4 * gl));
         }
-        const int64_t kmine = kg + gl;                   // the row whose results this lane will own
+        const int64_t kmine = kw + (int64_t)gl * Gw;     // the row whose results this lane will own
         const bool mine = gl < U && kmine < K;
         float pxz = 0.f;
         if (mine && iw_ll && log_p_x_z) pxz = log_p_x_z[b * K + kmine];
@@ -81,8 +87,8 @@ sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
                 }
                 lp += -0.5f * (LVAE_LOG_2PI + zz[e] * zz[e]);
             }
-            if (FROM_EPS && z_out && kg + u < K)
-                *reinterpret_cast<f32x4*>(z_out + (b * K + kg + u) * D + 4 * gl) = zz;
+            if (FROM_EPS && z_out && kw + u * Gw < K)
+                __builtin_nontemporal_store(zz, reinterpret_cast<f32x4*>(z_out + (b * K + kw + u * Gw) * D + 4 * gl));
             lq = group_sum(lq, G);
             lp = group_sum(lp, G);
             if (gl == u) {
