@@ -56,6 +56,17 @@ int lvae_version(void);
  * ------------------------------------------------------------------------------------------- */
 int lvae_log_qz_workspace_bytes(int64_t M, int64_t N, int D, int with_prod_marg, int64_t* out_bytes);
 
+/* Backward of lvae_log_qz_f32 (the reference differentiates approximate_log_q_z with autograd inside its
+ * training objectives, loss_and_optimisation.py:925-1018 via modules/encoder.py:102-107).
+ * Inputs: the forward inputs (logvar only), log_norm, the forward result log_qz [M] (needed with g_log_qz),
+ * and the upstream gradients g_log_qz [M] (on log_qz) and/or g_prod_marg [M] (on log_qz_prod_marg); either
+ * may be NULL.  Outputs (each may be NULL): d_z [M,D], d_mu [N,D], d_logvar [N,D].  The softmax weights are
+ * recomputed, nothing of size M x N is stored.  D <= 64; sized for training-time batches. */
+int lvae_log_qz_bwd_workspace_bytes(int64_t M, int64_t N, int D, int prod_marginals, int64_t* out_bytes);
+int lvae_log_qz_bwd_f32(const float* z, const float* mu, const float* logvar, int64_t M, int64_t N, int D,
+                        float log_norm, const float* log_qz, const float* g_log_qz, const float* g_prod_marg,
+                        float* d_z, float* d_mu, float* d_logvar, void* ws, int64_t ws_bytes, void* stream);
+
 /* Diagnostic (no counterpart in the reference): the launch plan of lvae_log_qz_f32 for these sizes.
  * out[8] = {padded latent dim of the MFMA path (0: unsupported), column blocks per wave, padded M, splits of
  * the posterior axis, 32-row blocks per split, splits of the direct path, 32-row blocks, workspace bytes}.

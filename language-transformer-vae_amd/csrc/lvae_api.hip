@@ -70,6 +70,18 @@ int lvae_launch_prep_labels(const unsigned char* labels, int P, int64_t n, int64
 int lvae_launch_perm_lr(const double* partial, const double* diag_partial, int nsplit, int64_t cpad, int64_t C,
                         const unsigned char* labels, int64_t n, int64_t col_offset, int P, int sym,
                         const double* qperm, double* out, hipStream_t st);
+int lvae_launch_finalize_pm_lse(const float2* partial, int nsplit, int64_t cpad, int64_t C, int DC,
+                                float* lse2, hipStream_t st);
+int lvae_launch_grad_records(const float* z, const float* log_qz, float log_norm, const float* g,
+                             const float* h, const float* lse2, int64_t M, int D, int DC, float* rec,
+                             hipStream_t st);
+int lvae_launch_grad_sample(const float* z, const float* dparams, const float* log_qz, float log_norm,
+                            const float* g, const float* h, const float* lse2, int64_t M, int64_t N, int D,
+                            int DC, int nsplit, int64_t rows_per_split, float* partial_dz, hipStream_t st);
+int lvae_launch_grad_posterior(const float* dparams, const float* rec, bool pm, int64_t M, int64_t N, int DC,
+                               int nsplit, int64_t rows_per_split, float* partial_dp, hipStream_t st);
+int lvae_launch_grad_reduce(const float* partial, int nsplit, int64_t rows, int stride, int off, int D,
+                            float* out, hipStream_t st);
 int lvae_launch_mmd_stat(const double* sums, int64_t n1, int64_t n2, int unbiased, int zero_alphas,
                          double* out, hipStream_t st);
 
@@ -306,6 +318,107 @@ extern "C" int lvae_log_qz_f32(const float* z, const float* mu, const float* spr
     LVAE_CHECK_ARG(log_qz || log_qz_prod_marg, "at least one of log_qz / log_qz_prod_marg is required");
     return run_log_qz(z, mu, spread, spread_kind, M, N, D, log_norm, exclude_diag, diag_offset, path,
                       log_qz, log_qz_prod_marg, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ---- backward of log q(z) / prod-marginals -------------------------------------------------------------
+struct GradLayout {
+    PairPlan p;
+    int nsA, nsB;                 // splits of the looped axis: posteriors (sample sweep), samples (posterior sweep)
+    int64_t rowsA, rowsB;
+    size_t off_lse, off_rec, off_pdz, off_pdp, total;
+};
+
+static int grad_splits(int64_t kept, int64_t looped, int64_t* rows) {
+    const int64_t waves = lvae_ceil_div(kept, 64);
+    int64_t ns = lvae_ceil_div(2048, waves);
+    const int64_t cap = lvae_ceil_div(looped, 16);
+    if (ns > cap) ns = cap;
+    if (ns > 64) ns = 64;
+    if (ns < 1) ns = 1;
+    *rows = lvae_ceil_div(looped, ns);
+    return (int)lvae_ceil_div(looped, *rows);
+}
+
+static GradLayout grad_layout(int64_t M, int64_t N, int D, bool pm) {
+    GradLayout g;
+    g.p = lvae_make_pair_plan(N, M, D, pm);
+    g.nsA = grad_splits(M, N, &g.rowsA);
+    g.nsB = grad_splits(N, M, &g.rowsB);
+    const int DC = g.p.DC;
+    size_t o = g.p.total;
+    g.off_lse = o; o = lvae_align256(o + (size_t)M * DC * sizeof(float));
+    g.off_rec = o; o = lvae_align256(o + (size_t)M * (2 * DC + 4) * sizeof(float));
+    g.off_pdz = o; o = lvae_align256(o + (size_t)g.nsA * M * DC * sizeof(float));
+    g.off_pdp = o; o = lvae_align256(o + (size_t)g.nsB * N * 2 * DC * sizeof(float));
+    g.total = o;
+    return g;
+}
+
+extern "C" int lvae_log_qz_bwd_workspace_bytes(int64_t M, int64_t N, int D, int prod_marginals,
+                                               int64_t* out_bytes) {
+    LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
+    LVAE_CHECK_ARG(M >= 1 && N >= 1 && D >= 1, "need M, N, D >= 1");
+    *out_bytes = (int64_t)grad_layout(M, N, D, prod_marginals != 0).total;
+    return LVAE_OK;
+}
+
+extern "C" int lvae_log_qz_bwd_f32(const float* z, const float* mu, const float* logvar, int64_t M, int64_t N,
+                                   int D, float log_norm, const float* log_qz, const float* g_log_qz,
+                                   const float* g_prod_marg, float* d_z, float* d_mu, float* d_logvar,
+                                   void* ws, int64_t ws_bytes, void* stream) {
+    int rc = check_pair_shapes(z, mu, logvar, LVAE_SPREAD_LOGVAR, M, N, D);
+    if (rc) return rc;
+    LVAE_CHECK_ARG(D <= 64, "the backward pass needs D <= 64 (got D=%d)", D);
+    LVAE_CHECK_ARG(g_log_qz || g_prod_marg, "at least one upstream gradient is required");
+    LVAE_CHECK_ARG(!g_log_qz || log_qz, "log_qz (the forward result) is required with g_log_qz");
+    LVAE_CHECK_ARG(d_z || d_mu || d_logvar, "at least one output gradient is required");
+    const bool pm = g_prod_marg != nullptr;
+    const GradLayout g = grad_layout(M, N, D, pm);
+    rc = check_ws(ws, ws_bytes, g.total);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const PairPlan& p = g.p;
+    char* base = (char*)ws;
+    float* dparams = (float*)(base + p.off_dparams);
+    float* lse2 = pm ? (float*)(base + g.off_lse) : nullptr;
+    float* rec = (float*)(base + g.off_rec);
+    float* pdz = (float*)(base + g.off_pdz);
+    float* pdp = (float*)(base + g.off_pdp);
+    rc = lvae_launch_prep_dparams(mu, logvar, LVAE_SPREAD_LOGVAR, N, D, p.DC, dparams, st);
+    if (rc) return rc;
+    if (pm) {   // per-(sample, dimension) logsumexp over the posteriors: the forward prod-marginals sweep
+        rc = lvae_launch_pair_direct(p, false, true, z, dparams, nullptr, (float2*)(base + p.off_dpartial_pm),
+                                     (int*)(base + p.off_dflags), (const PairHeader*)(base + p.off_hdr), -1.f, 0,
+                                     0, 0, st);
+        if (rc) return rc;
+        rc = lvae_launch_finalize_pm_lse((const float2*)(base + p.off_dpartial_pm), p.dsplit, p.cpad, M, p.DC,
+                                         lse2, st);
+        if (rc) return rc;
+    }
+    const float* gq = g_log_qz;
+    const float* lq = g_log_qz ? log_qz : nullptr;
+    if (d_z) {
+        rc = lvae_launch_grad_sample(z, dparams, lq, log_norm, gq, g_prod_marg, lse2, M, N, D, p.DC, g.nsA,
+                                     g.rowsA, pdz, st);
+        if (rc) return rc;
+        rc = lvae_launch_grad_reduce(pdz, g.nsA, M, p.DC, 0, D, d_z, st);
+        if (rc) return rc;
+    }
+    if (d_mu || d_logvar) {
+        rc = lvae_launch_grad_records(z, lq, log_norm, gq, g_prod_marg, lse2, M, D, p.DC, rec, st);
+        if (rc) return rc;
+        rc = lvae_launch_grad_posterior(dparams, rec, pm, M, N, p.DC, g.nsB, g.rowsB, pdp, st);
+        if (rc) return rc;
+        if (d_mu) {
+            rc = lvae_launch_grad_reduce(pdp, g.nsB, N, 2 * p.DC, 0, D, d_mu, st);
+            if (rc) return rc;
+        }
+        if (d_logvar) {
+            rc = lvae_launch_grad_reduce(pdp, g.nsB, N, 2 * p.DC, p.DC, D, d_logvar, st);
+            if (rc) return rc;
+        }
+    }
+    return LVAE_OK;
 }
 
 extern "C" int lvae_log_qz_partial_f32(const float* z, const float* mu, const float* spread,

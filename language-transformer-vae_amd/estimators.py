@@ -38,6 +38,46 @@ def log_qz_raw(mu, spread, latent_z, log_norm, prod_marginals=False, spread_kind
     return out, out_pm
 
 
+class _LogQz(torch.autograd.Function):
+    """log q(z) / prod-marginals with a HIP backward (lvae_log_qz_bwd_f32): the softmax weights are
+    recomputed from the saved forward result, like the forward nothing of size M x N is stored."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, z, log_norm, prod_marginals, path):
+        mu_d, lv_d, z_d = mu.detach(), logvar.detach(), z.detach()
+        lq, lqpm = log_qz_raw(mu_d, lv_d, z_d, log_norm, prod_marginals, path=path)
+        ctx.save_for_backward(N.as_f32(mu_d, "mu"), N.as_f32(lv_d, "logvar"), N.as_f32(z_d, "latent_z"), lq)
+        ctx.log_norm, ctx.prod_marginals = float(log_norm), bool(prod_marginals)
+        if lqpm is None:
+            lqpm = lq.new_zeros(())
+            ctx.mark_non_differentiable(lqpm)
+        return lq, lqpm
+
+    @staticmethod
+    def backward(ctx, g_lq, g_pm):
+        mu, logvar, z, lq = ctx.saved_tensors
+        Nn, D = mu.shape
+        M = z.shape[0]
+        dev = z.device
+        need_mu, need_lv, need_z = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        g_lq = None if g_lq is None else N.as_f32(g_lq.detach(), "grad").expand(M).contiguous()
+        g_pm = (None if (g_pm is None or not ctx.prod_marginals)
+                else N.as_f32(g_pm.detach(), "grad").expand(M).contiguous())
+        if g_lq is None and g_pm is None:
+            return None, None, None, None, None, None
+        with torch.cuda.device(dev):
+            nbytes = N._i64(0)
+            N.check(N.lib().lvae_log_qz_bwd_workspace_bytes(M, Nn, D, int(g_pm is not None), nbytes))
+            ws = N.workspace(nbytes.value, dev)
+            d_z = torch.empty_like(z) if need_z else None
+            d_mu = torch.empty_like(mu) if need_mu else None
+            d_lv = torch.empty_like(logvar) if need_lv else None
+            N.check(N.lib().lvae_log_qz_bwd_f32(N.ptr(z), N.ptr(mu), N.ptr(logvar), M, Nn, D, ctx.log_norm,
+                                                N.ptr(lq), N.ptr(g_lq), N.ptr(g_pm), N.ptr(d_z), N.ptr(d_mu),
+                                                N.ptr(d_lv), N.ptr(ws), nbytes.value, N.stream_ptr(dev)))
+        return d_mu, d_lv, d_z, None, None, None
+
+
 def approximate_log_q_z(mu, logvar, latent_z, method="chen", dataset_size=42068, prod_marginals=False,
                         reduce_mean=True, path=N.PATH_AUTO):
     """loss_and_optimisation.py:139-221.  mu, logvar [x_batch, D]; latent_z [z_batch, D].
@@ -48,6 +88,18 @@ def approximate_log_q_z(mu, logvar, latent_z, method="chen", dataset_size=42068,
         assert dataset_size is not None, "if using method 'chen', you need to provide a dataset size"
     x_batch = mu.shape[0]
     log_norm = math.log(x_batch * dataset_size) if method == "chen" else math.log(x_batch)   # :207,:215
+    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad
+                                       for t in (mu, logvar, latent_z)):
+        # training-time use (the objectives of :925-1018 differentiate this estimator): HIP forward and
+        # HIP backward behind torch.autograd; D <= 64
+        log_q_z, log_q_z_prod_marg = _LogQz.apply(mu, logvar, latent_z, log_norm, prod_marginals, path)
+        if not prod_marginals:
+            log_q_z_prod_marg = None
+        if reduce_mean:
+            if log_q_z_prod_marg is None:                # Q1
+                raise AttributeError("'NoneType' object has no attribute 'mean'")
+            return log_q_z.mean(), log_q_z_prod_marg.mean()
+        return log_q_z, log_q_z_prod_marg
     log_q_z, log_q_z_prod_marg = log_qz_raw(mu, logvar, latent_z, log_norm, prod_marginals, path=path)
     if reduce_mean:
         if log_q_z_prod_marg is None:                    # Q1, :219 -- ``None.mean()``

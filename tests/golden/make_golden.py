@@ -255,6 +255,35 @@ def case_mmd(lo, seed, n, D, name):
     print("wrote mmd", name, float(mmd))
 
 
+def case_grad(lo, name, seed, N, M, D, mode="generic"):
+    """Gradients of the reference's approximate_log_q_z under torch autograd (how its training objectives
+    use it, loss_and_optimisation.py:925-1018): loss = sum_i a_i log_qz_i + sum_i c_i log_qz_prod_marg_i."""
+    mu, logvar, z = gen_inputs(seed, N, M, D, mode)
+    g = torch.Generator().manual_seed(seed + 1000)
+    a = torch.randn(M, generator=g)
+    c = torch.randn(M, generator=g)
+    out = {"mu": np32(mu), "logvar": np32(logvar), "z": np32(z), "a": np32(a), "c": np32(c)}
+    for tag, wa, wc in (("joint", a, None), ("pm", None, c), ("both", a, c)):
+        mu_, lv_, z_ = (t.clone().requires_grad_(True) for t in (mu, logvar, z))
+        lq, lqpm = lo.approximate_log_q_z(mu_, lv_, z_, method="chen", dataset_size=10000,
+                                          prod_marginals=True, reduce_mean=False)
+        loss = 0.0
+        if wa is not None:
+            loss = loss + (wa * lq).sum()
+        if wc is not None:
+            loss = loss + (wc * lqpm).sum()
+        loss.backward()
+        out[f"d_mu_{tag}"], out[f"d_logvar_{tag}"], out[f"d_z_{tag}"] = np32(mu_.grad), np32(lv_.grad), np32(z_.grad)
+    # the mean-reduced form the objectives use: TC = mean(log_qz) - mean(log_qz_prod_marg)
+    mu_, lv_, z_ = (t.clone().requires_grad_(True) for t in (mu, logvar, z))
+    tc = lo.approximate_total_correlation(mu_, lv_, z_, method="chen", dataset_size=10000)
+    tc.backward()
+    out["tc"] = np32(tc)
+    out["d_mu_tc"], out["d_logvar_tc"], out["d_z_tc"] = np32(mu_.grad), np32(lv_.grad), np32(z_.grad)
+    np.savez_compressed(os.path.join(OUT, f"grad_{name}.npz"), **out)
+    print("wrote grad", name)
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference not present; nothing to do")
@@ -280,6 +309,11 @@ def main():
     case_kde(lo, kde, 16)
     case_mmd(lo, 17, 256, 32, "n256")
     case_mmd(lo, 18, 100, 64, "n100_d64")
+    case_grad(lo, "b32", 19, 32, 32, 32)
+    case_grad(lo, "ragged_d20", 20, 45, 70, 20)
+    case_grad(lo, "d64", 21, 96, 64, 64)
+    case_grad(lo, "n300", 22, 300, 300, 32)
+    case_grad(lo, "near_collapsed", 23, 64, 64, 32, "near_collapsed")
 
 
 if __name__ == "__main__":
