@@ -67,6 +67,20 @@ int lvae_log_qz_bwd_f32(const float* z, const float* mu, const float* logvar, in
                         float log_norm, const float* log_qz, const float* g_log_qz, const float* g_prod_marg,
                         float* d_z, float* d_mu, float* d_logvar, void* ws, int64_t ws_bytes, void* stream);
 
+/* Backward of lvae_sample_ll_f32 / lvae_sample_ll_elem_f32 (sample_log_likelihood under autograd,
+ * loss_and_optimisation.py:79-110): g is the upstream gradient per (b,k) [B,K] (g_per_element == 0) or per
+ * element [B,K,D]; mu == NULL selects the prior branch (only d_z).  Outputs may be NULL: d_z [B,K,D],
+ * d_mu, d_logvar [B,D]. */
+int lvae_sample_ll_bwd_f32(const float* z, const float* mu, const float* logvar, int64_t B, int64_t K, int D,
+                           const float* g, int g_per_element, float* d_z, float* d_mu, float* d_logvar,
+                           void* stream);
+
+/* Backward of lvae_kl_diag_f32 (kl_divergence under autograd, :14-43): g_kl / g_hinge are the upstream
+ * gradients of the two outputs, per element [N,D] (g_per_row == 0) or per row [N]; either may be NULL. */
+int lvae_kl_diag_bwd_f32(const float* mu, const float* logvar, int64_t N, int D, float lambda,
+                         const float* g_kl, const float* g_hinge, int g_per_row, float* d_mu, float* d_logvar,
+                         void* stream);
+
 /* Diagnostic (no counterpart in the reference): the launch plan of lvae_log_qz_f32 for these sizes.
  * out[8] = {padded latent dim of the MFMA path (0: unsupported), column blocks per wave, padded M, splits of
  * the posterior axis, 32-row blocks per split, splits of the direct path, 32-row blocks, workspace bytes}.

@@ -82,6 +82,12 @@ int lvae_launch_grad_posterior(const float* dparams, const float* rec, bool pm, 
                                int nsplit, int64_t rows_per_split, float* partial_dp, hipStream_t st);
 int lvae_launch_grad_reduce(const float* partial, int nsplit, int64_t rows, int stride, int off, int D,
                             float* out, hipStream_t st);
+int lvae_launch_sample_ll_bwd(const float* z, const float* mu, const float* logvar, const float* g, int g_elem,
+                              int64_t B, int64_t K, int D, float* d_z, float* d_mu, float* d_logvar,
+                              hipStream_t st);
+int lvae_launch_kl_bwd(const float* mu, const float* logvar, const float* g_kl, const float* g_hinge,
+                       int row_mode, int64_t n, int D, float lambda, float* d_mu, float* d_logvar,
+                       hipStream_t st);
 int lvae_launch_mmd_stat(const double* sums, int64_t n1, int64_t n2, int unbiased, int zero_alphas,
                          double* out, hipStream_t st);
 
@@ -318,6 +324,30 @@ extern "C" int lvae_log_qz_f32(const float* z, const float* mu, const float* spr
     LVAE_CHECK_ARG(log_qz || log_qz_prod_marg, "at least one of log_qz / log_qz_prod_marg is required");
     return run_log_qz(z, mu, spread, spread_kind, M, N, D, log_norm, exclude_diag, diag_offset, path,
                       log_qz, log_qz_prod_marg, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ---- backward of the element-wise estimators -------------------------------------------------------------
+extern "C" int lvae_sample_ll_bwd_f32(const float* z, const float* mu, const float* logvar, int64_t B, int64_t K,
+                                      int D, const float* g, int g_per_element, float* d_z, float* d_mu,
+                                      float* d_logvar, void* stream) {
+    LVAE_CHECK_ARG(z && g, "z and g must be non-NULL");
+    LVAE_CHECK_ARG((mu == nullptr) == (logvar == nullptr), "mu and logvar must be given together");
+    LVAE_CHECK_ARG(B >= 1 && K >= 1 && D >= 1, "need B, K, D >= 1");
+    LVAE_CHECK_ARG(d_z || d_mu || d_logvar, "at least one output gradient is required");
+    LVAE_CHECK_ARG(mu || (!d_mu && !d_logvar), "the prior branch has no mu / logvar gradients");
+    return lvae_launch_sample_ll_bwd(z, mu, logvar, g, g_per_element != 0, B, K, D, d_z, d_mu, d_logvar,
+                                     (hipStream_t)stream);
+}
+
+extern "C" int lvae_kl_diag_bwd_f32(const float* mu, const float* logvar, int64_t N, int D, float lambda,
+                                    const float* g_kl, const float* g_hinge, int g_per_row, float* d_mu,
+                                    float* d_logvar, void* stream) {
+    LVAE_CHECK_ARG(mu && logvar, "mu and logvar must be non-NULL");
+    LVAE_CHECK_ARG(N >= 1 && D >= 1, "need N, D >= 1");
+    LVAE_CHECK_ARG(g_kl || g_hinge, "at least one upstream gradient is required");
+    LVAE_CHECK_ARG(d_mu || d_logvar, "at least one output gradient is required");
+    return lvae_launch_kl_bwd(mu, logvar, g_kl, g_hinge, g_per_row != 0, N, D, lambda, d_mu, d_logvar,
+                              (hipStream_t)stream);
 }
 
 // ---- backward of log q(z) / prod-marginals -------------------------------------------------------------

@@ -88,8 +88,7 @@ def approximate_log_q_z(mu, logvar, latent_z, method="chen", dataset_size=42068,
         assert dataset_size is not None, "if using method 'chen', you need to provide a dataset size"
     x_batch = mu.shape[0]
     log_norm = math.log(x_batch * dataset_size) if method == "chen" else math.log(x_batch)   # :207,:215
-    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad
-                                       for t in (mu, logvar, latent_z)):
+    if _needs_grad(mu, logvar, latent_z):
         # training-time use (the objectives of :925-1018 differentiate this estimator): HIP forward and
         # HIP backward behind torch.autograd; D <= 64
         log_q_z, log_q_z_prod_marg = _LogQz.apply(mu, logvar, latent_z, log_norm, prod_marginals, path)
@@ -109,15 +108,11 @@ def approximate_log_q_z(mu, logvar, latent_z, method="chen", dataset_size=42068,
     return log_q_z, log_q_z_prod_marg
 
 
-def sample_log_likelihood(latent_z, mu=None, logvar=None, reduce_latent_dim=True, reduce_batch_dim=True):
-    """loss_and_optimisation.py:79-110.  Log-density of samples under the posterior N(mu, exp(logvar))
-    (both given) or the standard-normal prior (neither given).
-    Supported layouts: latent_z [B,K,D] with mu/logvar [B,D] or [B,1,D] (:86-90), latent_z [M,D] with
-    mu/logvar [M,D], and any [..., D] for the prior."""
+def _sample_ll_args(latent_z, mu, logvar):
+    """Validated float32 views and the (B, K, D) geometry of one sample_log_likelihood call."""
     z = N.as_f32(latent_z, "latent_z")
     post = mu is not None and logvar is not None
     D = z.shape[-1]
-    dev = z.device
     if post:
         mu, logvar = N.as_f32(mu, "mu"), N.as_f32(logvar, "logvar")
         if z.dim() == 3:
@@ -136,6 +131,12 @@ def sample_log_likelihood(latent_z, mu=None, logvar=None, reduce_latent_dim=True
     else:
         mu2 = lv2 = None
         B, K = z.numel() // D, 1
+    return z, mu2, lv2, B, K, D
+
+
+def _sample_ll_forward(z, mu2, lv2, B, K, D, reduce_latent_dim):
+    dev = z.device
+    post = mu2 is not None
     with torch.cuda.device(dev):
         if reduce_latent_dim:
             out = torch.empty(z.shape[:-1], dtype=torch.float32, device=dev)
@@ -146,29 +147,122 @@ def sample_log_likelihood(latent_z, mu=None, logvar=None, reduce_latent_dim=True
             out = torch.empty_like(z)
             N.check(N.lib().lvae_sample_ll_elem_f32(N.ptr(z), N.ptr(mu2), N.ptr(lv2), B, K, D, N.ptr(out),
                                                     N.stream_ptr(dev)))
+    return out
+
+
+class _SampleLL(torch.autograd.Function):
+    """sample_log_likelihood with a HIP backward (lvae_sample_ll_bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, latent_z, mu, logvar, reduce_latent_dim):
+        det = lambda t: None if t is None else t.detach()
+        z, mu2, lv2, B, K, D = _sample_ll_args(det(latent_z), det(mu), det(logvar))
+        ctx.geom = (B, K, D, bool(reduce_latent_dim), latent_z.shape,
+                    None if mu is None else mu.shape, None if logvar is None else logvar.shape)
+        ctx.save_for_backward(z, mu2, lv2)
+        return _sample_ll_forward(z, mu2, lv2, B, K, D, reduce_latent_dim)
+
+    @staticmethod
+    def backward(ctx, g):
+        z, mu2, lv2 = ctx.saved_tensors
+        B, K, D, red, zshape, mushape, lvshape = ctx.geom
+        dev = z.device
+        g = N.as_f32(g.detach(), "grad").expand(z.shape[:-1] if red else z.shape).contiguous()
+        need_z, need_mu, need_lv = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        post = mu2 is not None
+        with torch.cuda.device(dev):
+            d_z = torch.empty_like(z) if need_z else None
+            d_mu = torch.empty_like(mu2) if (post and need_mu) else None
+            d_lv = torch.empty_like(lv2) if (post and need_lv) else None
+            if d_z is not None or d_mu is not None or d_lv is not None:
+                N.check(N.lib().lvae_sample_ll_bwd_f32(N.ptr(z), N.ptr(mu2), N.ptr(lv2), B, K, D, N.ptr(g),
+                                                       0 if red else 1, N.ptr(d_z), N.ptr(d_mu), N.ptr(d_lv),
+                                                       N.stream_ptr(dev)))
+        return (None if d_z is None else d_z.reshape(zshape), None if d_mu is None else d_mu.reshape(mushape),
+                None if d_lv is None else d_lv.reshape(lvshape), None)
+
+
+def _needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
+
+
+def sample_log_likelihood(latent_z, mu=None, logvar=None, reduce_latent_dim=True, reduce_batch_dim=True):
+    """loss_and_optimisation.py:79-110.  Log-density of samples under the posterior N(mu, exp(logvar))
+    (both given) or the standard-normal prior (neither given).
+    Supported layouts: latent_z [B,K,D] with mu/logvar [B,D] or [B,1,D] (:86-90), latent_z [M,D] with
+    mu/logvar [M,D], and any [..., D] for the prior.  Differentiable (HIP backward) when an input
+    requires grad."""
+    if mu is None or logvar is None:
+        mu = logvar = None
+    if _needs_grad(latent_z, mu, logvar):
+        out = _SampleLL.apply(latent_z, mu, logvar, reduce_latent_dim)
+        return out.mean(dim=0) if reduce_batch_dim else out          # :107-108
+    z, mu2, lv2, B, K, D = _sample_ll_args(latent_z, mu, logvar)
+    out = _sample_ll_forward(z, mu2, lv2, B, K, D, reduce_latent_dim)
     if reduce_batch_dim:                                  # :107-108 mean over dim 0
         return N.mean_f32(out) if out.dim() <= 1 else N.colmean_f32(out)
     return out
 
 
-def kl_divergence(mu, logvar, hinge_kl_loss_lambda=0.5, average_batch=True, sum_latent=True):
-    """loss_and_optimisation.py:14-43.  Returns (kl_loss, hinge_kl_loss) with the reference's shapes:
-    0-dim (sum_latent, average_batch), [N] (sum_latent only), [D] (average_batch only) or [N,D]."""
-    mu, logvar = N.as_f32(mu, "mu"), N.as_f32(logvar, "logvar")
-    if mu.dim() != 2 or mu.shape != logvar.shape:
-        raise ValueError("mu and logvar must be [batch, latent] of one shape")
+def _kl_forward(mu, logvar, lam, sum_latent):
     n, D = mu.shape
     dev = mu.device
     with torch.cuda.device(dev):
         if sum_latent:
             kl = torch.empty(n, dtype=torch.float32, device=dev)
             hk = torch.empty(n, dtype=torch.float32, device=dev)
-            N.check(N.lib().lvae_kl_diag_f32(N.ptr(mu), N.ptr(logvar), n, D, float(hinge_kl_loss_lambda),
+            N.check(N.lib().lvae_kl_diag_f32(N.ptr(mu), N.ptr(logvar), n, D, float(lam),
                                              None, None, N.ptr(kl), N.ptr(hk), N.stream_ptr(dev)))
         else:
             kl, hk = torch.empty_like(mu), torch.empty_like(mu)
-            N.check(N.lib().lvae_kl_diag_f32(N.ptr(mu), N.ptr(logvar), n, D, float(hinge_kl_loss_lambda),
+            N.check(N.lib().lvae_kl_diag_f32(N.ptr(mu), N.ptr(logvar), n, D, float(lam),
                                              N.ptr(kl), N.ptr(hk), None, None, N.stream_ptr(dev)))
+    return kl, hk
+
+
+class _KL(torch.autograd.Function):
+    """kl_divergence ([N] rows or [N,D] elements) with a HIP backward (lvae_kl_diag_bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, lam, sum_latent):
+        mu_d, lv_d = N.as_f32(mu.detach(), "mu"), N.as_f32(logvar.detach(), "logvar")
+        ctx.save_for_backward(mu_d, lv_d)
+        ctx.lam, ctx.sum_latent = float(lam), bool(sum_latent)
+        return _kl_forward(mu_d, lv_d, lam, sum_latent)
+
+    @staticmethod
+    def backward(ctx, g_kl, g_hk):
+        mu, logvar = ctx.saved_tensors
+        n, D = mu.shape
+        dev = mu.device
+        shape = (n,) if ctx.sum_latent else (n, D)
+        fix = lambda g: None if g is None else N.as_f32(g.detach(), "grad").expand(shape).contiguous()
+        g_kl, g_hk = fix(g_kl), fix(g_hk)
+        if g_kl is None and g_hk is None:
+            return None, None, None, None
+        with torch.cuda.device(dev):
+            d_mu = torch.empty_like(mu) if ctx.needs_input_grad[0] else None
+            d_lv = torch.empty_like(logvar) if ctx.needs_input_grad[1] else None
+            if d_mu is not None or d_lv is not None:
+                N.check(N.lib().lvae_kl_diag_bwd_f32(N.ptr(mu), N.ptr(logvar), n, D, ctx.lam, N.ptr(g_kl),
+                                                     N.ptr(g_hk), int(ctx.sum_latent), N.ptr(d_mu), N.ptr(d_lv),
+                                                     N.stream_ptr(dev)))
+        return d_mu, d_lv, None, None
+
+
+def kl_divergence(mu, logvar, hinge_kl_loss_lambda=0.5, average_batch=True, sum_latent=True):
+    """loss_and_optimisation.py:14-43.  Returns (kl_loss, hinge_kl_loss) with the reference's shapes:
+    0-dim (sum_latent, average_batch), [N] (sum_latent only), [D] (average_batch only) or [N,D].
+    Differentiable (HIP backward) when mu or logvar requires grad."""
+    if _needs_grad(mu, logvar):
+        if mu.dim() != 2 or mu.shape != logvar.shape:
+            raise ValueError("mu and logvar must be [batch, latent] of one shape")
+        kl, hk = _KL.apply(mu, logvar, hinge_kl_loss_lambda, sum_latent)
+        return (kl.mean(dim=0), hk.mean(dim=0)) if average_batch else (kl, hk)
+    mu, logvar = N.as_f32(mu, "mu"), N.as_f32(logvar, "logvar")
+    if mu.dim() != 2 or mu.shape != logvar.shape:
+        raise ValueError("mu and logvar must be [batch, latent] of one shape")
+    kl, hk = _kl_forward(mu, logvar, hinge_kl_loss_lambda, sum_latent)
     if average_batch:
         if sum_latent:
             return N.mean_f32(kl), N.mean_f32(hk)
@@ -196,7 +290,7 @@ def gaussian_kernel(x, y):
     full [n, m] matrix.  Like the reference's ``torch.tensor(...)`` wrap (:76, quirk Q5) the result carries
     no gradient."""
     dim = x.shape[1]
-    return _kernel_matrix(x, y, [1.0 / float(dim * dim)], 0.0)
+    return _kernel_matrix(x.detach(), y.detach(), [1.0 / float(dim * dim)], 0.0)
 
 
 def mmd_rbf(x, y, alphas, dist_eps, unbiased):
@@ -322,7 +416,8 @@ def maximum_mean_discrepancy(latent_z, prior_sample=None):
     """loss_and_optimisation.py:46-60: biased RBF MMD between a standard-normal draw x and latent_z:
     mean(Kxx) + mean(Kyy) - 2 mean(Kxy).  The reference draws ``x = randn_like(latent_z)`` inside (:53);
     pass ``prior_sample`` to inject it (parity tests), otherwise it is drawn here the same way."""
-    x = torch.randn_like(latent_z) if prior_sample is None else prior_sample
+    latent_z = latent_z.detach()      # quirk Q5: the reference's kernel detaches (torch.tensor(...), :76) -> no gradient
+    x = torch.randn_like(latent_z) if prior_sample is None else prior_sample.detach()
     D = latent_z.shape[1]
     return mmd_rbf(x, latent_z, [1.0 / float(D * D)], 0.0, unbiased=False)[0].float()
 

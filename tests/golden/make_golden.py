@@ -284,6 +284,39 @@ def case_grad(lo, name, seed, N, M, D, mode="generic"):
     print("wrote grad", name)
 
 
+def case_grad_elem(lo, seed, B, K, D):
+    """Gradients of sample_log_likelihood (posterior / prior, reduced / element-wise) and kl_divergence."""
+    g = torch.Generator().manual_seed(seed)
+    mu = torch.randn(B, D, generator=g)
+    logvar = 0.5 * torch.randn(B, D, generator=g) - 1.0
+    z = mu.unsqueeze(1) + torch.randn(B, K, D, generator=g) * torch.exp(0.5 * logvar).unsqueeze(1)
+    w_bk = torch.randn(B, K, generator=g)
+    w_bkd = torch.randn(B, K, D, generator=g)
+    out = {"mu": np32(mu), "logvar": np32(logvar), "z": np32(z), "w_bk": np32(w_bk), "w_bkd": np32(w_bkd)}
+
+    def run(tag, fn):
+        mu_, lv_, z_ = (t.clone().requires_grad_(True) for t in (mu, logvar, z))
+        val = fn(mu_, lv_, z_)
+        val.backward()
+        out[f"val_{tag}"] = np32(val)
+        for nm, t in (("mu", mu_), ("logvar", lv_), ("z", z_)):
+            out[f"d_{nm}_{tag}"] = np32(t.grad) if t.grad is not None else np.zeros(t.shape, np.float32)
+
+    run("post_red", lambda m, l, zz: (w_bk * lo.sample_log_likelihood(zz, m, l, True, False)).sum())
+    run("post_elem", lambda m, l, zz: (w_bkd * lo.sample_log_likelihood(zz, m, l, False, False)).sum())
+    run("post_mean", lambda m, l, zz: lo.sample_log_likelihood(zz, m, l).sum())
+    run("prior_red", lambda m, l, zz: (w_bk * lo.sample_log_likelihood(zz, reduce_batch_dim=False)).sum())
+    run("post_2d", lambda m, l, zz: (w_bk[:, 0] * lo.sample_log_likelihood(zz[:, 0], m, l, True, False)).sum())
+    for lam in (0.0, 0.5):
+        run(f"kl_lam{lam}", lambda m, l, zz: sum(a * b for a, b in zip((1.0, 0.7), lo.kl_divergence(m, l, lam))))
+        run(f"kl_rows_lam{lam}", lambda m, l, zz: sum((w_bk[:, 0] * t).sum() * c for t, c in zip(
+            lo.kl_divergence(m, l, lam, average_batch=False, sum_latent=True), (1.0, -0.3))))
+        run(f"kl_elem_lam{lam}", lambda m, l, zz: sum((w_bkd[:, 0] * t).sum() * c for t, c in zip(
+            lo.kl_divergence(m, l, lam, average_batch=False, sum_latent=False), (0.4, 1.0))))
+    np.savez_compressed(os.path.join(OUT, "grad_elem.npz"), **out)
+    print("wrote grad_elem")
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference not present; nothing to do")
@@ -314,6 +347,7 @@ def main():
     case_grad(lo, "d64", 21, 96, 64, 64)
     case_grad(lo, "n300", 22, 300, 300, 32)
     case_grad(lo, "near_collapsed", 23, 64, 64, 32, "near_collapsed")
+    case_grad_elem(lo, 24, 12, 5, 32)
 
 
 if __name__ == "__main__":

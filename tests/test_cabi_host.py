@@ -96,8 +96,10 @@ def test_no_cpu_fallback():
     zg = torch.zeros(4, 32, requires_grad=True)
     with pytest.raises(N.LvaeError, match="no CPU fallback"):       # differentiable path: HIP only as well
         E.approximate_log_q_z(zg, lv, z, prod_marginals=True)
-    with pytest.raises(N.LvaeError, match="forward-only"):          # estimators without a backward say so
+    with pytest.raises(N.LvaeError, match="no CPU fallback"):
         E.sample_log_likelihood(zg, mu, lv)
+    with pytest.raises(N.LvaeError, match="forward-only"):          # estimators without a backward say so
+        MI.calc_upper_and_lower_bound_representational_mi(zg, torch.zeros(4, 64))
 
 
 def test_missing_library_is_an_error(monkeypatch):
