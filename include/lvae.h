@@ -75,6 +75,11 @@ int lvae_sample_ll_bwd_f32(const float* z, const float* mu, const float* logvar,
                            const float* g, int g_per_element, float* d_z, float* d_mu, float* d_logvar,
                            void* stream);
 
+/* Backward of the sampling step of lvae_reparam_iw_f32 (reparameterize, modules/encoder.py:148-157):
+ * g_z [B,K,D] -> d_mu, d_logvar [B,D] (either may be NULL). */
+int lvae_reparam_bwd_f32(const float* logvar, const float* eps, const float* g_z, int64_t B, int64_t K, int D,
+                         float* d_mu, float* d_logvar, void* stream);
+
 /* Backward of lvae_kl_diag_f32 (kl_divergence under autograd, :14-43): g_kl / g_hinge are the upstream
  * gradients of the two outputs, per element [N,D] (g_per_row == 0) or per row [N]; either may be NULL. */
 int lvae_kl_diag_bwd_f32(const float* mu, const float* logvar, int64_t N, int D, float lambda,

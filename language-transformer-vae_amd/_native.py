@@ -63,6 +63,8 @@ _SIGNATURES = {
                                    _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p, _i64, ctypes.c_void_p]),
     "lvae_sample_ll_bwd_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _i64, _int, _c_f32p, _int, _c_f32p,
                                       _c_f32p, _c_f32p, ctypes.c_void_p]),
+    "lvae_reparam_bwd_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _i64, _int, _c_f32p, _c_f32p,
+                                    ctypes.c_void_p]),
     "lvae_kl_diag_bwd_f32": (_int, [_c_f32p, _c_f32p, _i64, _int, _f32, _c_f32p, _c_f32p, _int, _c_f32p,
                                     _c_f32p, ctypes.c_void_p]),
     "lvae_plan_info": (_int, [_i64, _i64, _int, _int, ctypes.POINTER(_i64)]),

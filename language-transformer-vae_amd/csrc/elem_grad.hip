@@ -86,3 +86,31 @@ int lvae_launch_kl_bwd(const float* mu, const float* logvar, const float* g_kl, 
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }
+
+// reparameterize (modules/encoder.py:148-157): z = mu + eps * exp(0.5 logvar).
+// d mu[b,d] = sum_k g[b,k,d] ;  d logvar[b,d] = 0.5 exp(0.5 logvar) sum_k g[b,k,d] eps[b,k,d].
+__global__ void __launch_bounds__(256)
+reparam_bwd_kernel(const float* __restrict__ logvar, const float* __restrict__ eps,
+                   const float* __restrict__ g, int64_t B, int64_t K, int D, float* __restrict__ d_mu,
+                   float* __restrict__ d_logvar) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * D) return;
+    const int64_t b = idx / D;
+    const int d = (int)(idx - b * D);
+    float am = 0.f, al = 0.f;
+    for (int64_t k = 0; k < K; ++k) {
+        const int64_t e = (b * K + k) * D + d;
+        am += g[e];
+        al = fmaf(g[e], eps[e], al);
+    }
+    if (d_mu) d_mu[idx] = am;
+    if (d_logvar) d_logvar[idx] = 0.5f * expf(0.5f * logvar[idx]) * al;
+}
+
+int lvae_launch_reparam_bwd(const float* logvar, const float* eps, const float* g, int64_t B, int64_t K, int D,
+                            float* d_mu, float* d_logvar, hipStream_t st) {
+    hipLaunchKernelGGL(reparam_bwd_kernel, dim3((unsigned)lvae_ceil_div(B * D, 256)), dim3(256), 0, st, logvar,
+                       eps, g, B, K, D, d_mu, d_logvar);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}

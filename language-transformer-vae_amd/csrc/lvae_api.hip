@@ -85,6 +85,8 @@ int lvae_launch_grad_reduce(const float* partial, int nsplit, int64_t rows, int 
 int lvae_launch_sample_ll_bwd(const float* z, const float* mu, const float* logvar, const float* g, int g_elem,
                               int64_t B, int64_t K, int D, float* d_z, float* d_mu, float* d_logvar,
                               hipStream_t st);
+int lvae_launch_reparam_bwd(const float* logvar, const float* eps, const float* g, int64_t B, int64_t K, int D,
+                            float* d_mu, float* d_logvar, hipStream_t st);
 int lvae_launch_kl_bwd(const float* mu, const float* logvar, const float* g_kl, const float* g_hinge,
                        int row_mode, int64_t n, int D, float lambda, float* d_mu, float* d_logvar,
                        hipStream_t st);
@@ -337,6 +339,14 @@ extern "C" int lvae_sample_ll_bwd_f32(const float* z, const float* mu, const flo
     LVAE_CHECK_ARG(mu || (!d_mu && !d_logvar), "the prior branch has no mu / logvar gradients");
     return lvae_launch_sample_ll_bwd(z, mu, logvar, g, g_per_element != 0, B, K, D, d_z, d_mu, d_logvar,
                                      (hipStream_t)stream);
+}
+
+extern "C" int lvae_reparam_bwd_f32(const float* logvar, const float* eps, const float* g_z, int64_t B, int64_t K,
+                                   int D, float* d_mu, float* d_logvar, void* stream) {
+    LVAE_CHECK_ARG(logvar && eps && g_z, "logvar, eps and g_z must be non-NULL");
+    LVAE_CHECK_ARG(B >= 1 && K >= 1 && D >= 1, "need B, K, D >= 1");
+    LVAE_CHECK_ARG(d_mu || d_logvar, "at least one output gradient is required");
+    return lvae_launch_reparam_bwd(logvar, eps, g_z, B, K, D, d_mu, d_logvar, (hipStream_t)stream);
 }
 
 extern "C" int lvae_kl_diag_bwd_f32(const float* mu, const float* logvar, int64_t N, int D, float lambda,

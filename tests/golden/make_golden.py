@@ -317,6 +317,35 @@ def case_grad_elem(lo, seed, B, K, D):
     print("wrote grad_elem")
 
 
+def case_grad_encode_tail(lo, seed, B, K, D):
+    """The op sequence of EncoderNewsVAE.encode after the transformer (modules/encoder.py:79-107) with
+    injected eps, combined into a beta-TC-VAE style scalar (MI, TC, dimension-wise KL with weights, cf.
+    loss_and_optimisation.py:816-824,:925-966) plus the analytic KL, and its gradients w.r.t. mu, logvar."""
+    g = torch.Generator().manual_seed(seed)
+    mu = torch.randn(B, D, generator=g).requires_grad_(True)
+    logvar = (0.5 * torch.randn(B, D, generator=g) - 1.0).requires_grad_(True)
+    eps = torch.randn(B, K, D, generator=g)
+    std = logvar.mul(0.5).exp()
+    latent_z = mu.unsqueeze(1) + eps * std.unsqueeze(1)                       # reparameterize :148-157
+    single = latent_z[:, 0, :]
+    log_q_z_x = lo.sample_log_likelihood(latent_z, mu=mu, logvar=logvar, reduce_latent_dim=True,
+                                         reduce_batch_dim=False)
+    log_p_z = lo.sample_log_likelihood(latent_z, reduce_latent_dim=True, reduce_batch_dim=False)
+    log_q_z, log_q_z_pm = lo.approximate_log_q_z(mu, logvar, single, method="chen", dataset_size=10000,
+                                                 prod_marginals=True)
+    kl, hinge = lo.kl_divergence(mu, logvar, hinge_kl_loss_lambda=0.5)
+    mi = log_q_z_x.mean() - log_q_z
+    tc = log_q_z - log_q_z_pm
+    dim_kl = log_q_z_pm - log_p_z.mean()
+    loss = 1.0 * mi + 3.0 * tc + 0.5 * dim_kl + 0.25 * kl + 0.1 * hinge
+    loss.backward()
+    out = {"mu": np32(mu), "logvar": np32(logvar), "eps": np32(eps), "loss": np32(loss), "mi": np32(mi),
+           "tc": np32(tc), "dim_kl": np32(dim_kl), "kl": np32(kl), "hinge": np32(hinge),
+           "d_mu": np32(mu.grad), "d_logvar": np32(logvar.grad)}
+    np.savez_compressed(os.path.join(OUT, "grad_encode_tail.npz"), **out)
+    print("wrote grad_encode_tail")
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference not present; nothing to do")
@@ -348,6 +377,7 @@ def main():
     case_grad(lo, "n300", 22, 300, 300, 32)
     case_grad(lo, "near_collapsed", 23, 64, 64, 32, "near_collapsed")
     case_grad_elem(lo, 24, 12, 5, 32)
+    case_grad_encode_tail(lo, 25, 32, 3, 32)
 
 
 if __name__ == "__main__":
