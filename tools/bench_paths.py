@@ -1,8 +1,8 @@
 """Secondary-path measurements (not the bench.py contract): IW reduction (C5), MMD statistic, prod-marginals,
 D=64 pair kernel.  Prints one line per path with the achieved rate against its roofline."""
-import sys, time
+import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lvae import estimators as E, _native as N
 from lvae.two_sample import MMDStatistic
 
