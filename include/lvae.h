@@ -184,10 +184,13 @@ int lvae_colmean_f32(const float* x, int64_t n, int64_t c, float* out, void* ws,
                      void* stream);
 
 /* GaussianKDE.score_samples (utils_latent_analysis_optimisation.py:33-60): X [n,d] fit points, Y [m,d]
- * queries, bandwidth bw; out[j] = log(bw^-d * sum_i exp(logN((X_i - Y_j)/bw)) / n), float32 and
- * unstabilised like the reference (quirk Q6: -inf when every term underflows). */
-int lvae_kde_score_f32(const float* X, const float* Y, int64_t n, int64_t m, int d, float bw, float* out,
-                       void* stream);
+ * queries, bandwidth bw; out[j] = log(bw^-d * sum_i exp(logN((X_i - Y_j)/bw)) / n), float32.
+ * stabilise == 0: plain sum like the reference (quirk Q6: -inf when every term underflows);
+ * stabilise != 0 (no counterpart in the reference; for dataset-scale use): the sum is taken relative to the
+ * largest term (one extra pass without exponentials), finite for any query. */
+int lvae_kde_workspace_bytes(int64_t n, int64_t m, int64_t* out_bytes);
+int lvae_kde_score_f32(const float* X, const float* Y, int64_t n, int64_t m, int d, float bw, int stabilise,
+                       float* out, void* ws, int64_t ws_bytes, void* stream);
 
 /* Gaussian-kernel MMD two-sample statistic with a sum of bandwidths:
  *     k(a, b) = sum_k exp(-alphas[k] * (dist_eps + |a - b|^2))

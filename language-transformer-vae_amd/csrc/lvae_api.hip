@@ -49,8 +49,9 @@ int lvae_launch_finalize_ksum(const double* partial, int nsplit, int64_t cpad, i
 int lvae_launch_kl(const float* mu, const float* logvar, int64_t n, int D, float lambda, float* kl_elem,
                    float* hinge_elem, float* kl_row, float* hinge_row, hipStream_t st);
 int lvae_launch_colmean(const float* x, int64_t n, int64_t c, float* out, double* acc, hipStream_t st);
-int lvae_launch_kde(const float* X, const float* Y, int64_t n, int64_t m, int d, float bw, float* out,
-                    hipStream_t st);
+void lvae_kde_plan(int64_t n, int64_t m, int* nsplit, int64_t* rows);
+int lvae_launch_kde(const float* X, const float* Y, int64_t n, int64_t m, int d, float bw, int stabilise,
+                    float* out, float* ws, hipStream_t st);
 int lvae_launch_pair_matrix(const float* a, const float* spread, int spread_kind, const float* b,
                             int64_t na, int64_t nb, int D, int mode, const PairHeader* hdr, float* out,
                             hipStream_t st);
@@ -633,12 +634,27 @@ extern "C" int lvae_colmean_f32(const float* x, int64_t n, int64_t c, float* out
     return lvae_launch_colmean(x, n, c, out, (double*)ws, (hipStream_t)stream);
 }
 
+extern "C" int lvae_kde_workspace_bytes(int64_t n, int64_t m, int64_t* out_bytes) {
+    LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
+    LVAE_CHECK_ARG(n >= 1 && m >= 1, "need n, m >= 1");
+    int nsplit;
+    int64_t rows;
+    lvae_kde_plan(n, m, &nsplit, &rows);
+    *out_bytes = (int64_t)(((size_t)nsplit + 1) * m * sizeof(float));
+    return LVAE_OK;
+}
+
 extern "C" int lvae_kde_score_f32(const float* X, const float* Y, int64_t n, int64_t m, int d, float bw,
-                                  float* out, void* stream) {
+                                  int stabilise, float* out, void* ws, int64_t ws_bytes, void* stream) {
     LVAE_CHECK_ARG(X && Y && out, "NULL pointer");
     LVAE_CHECK_ARG(n >= 1 && m >= 1 && d >= 1, "need n, m, d >= 1");
     LVAE_CHECK_ARG(bw > 0.f, "bandwidth must be positive");
-    return lvae_launch_kde(X, Y, n, m, d, bw, out, (hipStream_t)stream);
+    int nsplit;
+    int64_t rows;
+    lvae_kde_plan(n, m, &nsplit, &rows);
+    int rc = check_ws(ws, ws_bytes, ((size_t)nsplit + 1) * m * sizeof(float));
+    if (rc) return rc;
+    return lvae_launch_kde(X, Y, n, m, d, bw, stabilise, out, (float*)ws, (hipStream_t)stream);
 }
 
 // ---- MMD -----------------------------------------------------------------------------------------------

@@ -70,38 +70,146 @@ int lvae_launch_colmean(const float* x, int64_t n, int64_t c, float* out, double
 }
 
 // ---- Gaussian KDE scores (utils_latent_analysis_optimisation.py:55-58) ---------------------------
-// out[j] = log( bw^-d * sum_i exp(logN((X_i - Y_j)/bw; 0, I)) / n ), float32 and UNstabilised like the
-// reference (quirk Q6: a query far from every point gives log(0) = -inf).
+// out[j] = log( bw^-d * sum_i exp(logN((X_i - Y_j)/bw; 0, I)) / n ), float32.  Lane = query, the fit points
+// are wave-uniform (scalar loads).  Base-2 form: term_ij = exp2(c0 - sum_d ((x_id - y_jd) s)^2) with
+// s = sqrt(0.5 log2e) / bw and c0 = -0.5 d log2(2 pi).
+// stabilise == 0: plain sum like the reference (quirk Q6: a query far from every point underflows to
+//                 log(0) = -inf);
+// stabilise != 0: `ref` [m] holds max_i of the exponent (first pass, KDE_MAXPASS), the sum is taken relative
+//                 to it and the result is finite for any query.
+// d == 1 (get_1d_kde_dim_marg_kl_estimate, loss_and_optimisation.py:625-637) takes two fit points per
+// packed fp32 instruction: 2 VALU slots + one v_exp_f32 per pair.
+template <bool MAXPASS>
 __global__ void __launch_bounds__(256)
-kde_score_kernel(const float* __restrict__ X, const float* __restrict__ Y, int64_t n, int64_t m, int d,
-                 float bw, float* __restrict__ out) {
+kde_1d_kernel(const float* __restrict__ X, const float* __restrict__ Y, int64_t n, int64_t m, float bw,
+              int64_t rows_per_split, const float* __restrict__ ref, float* __restrict__ partial) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t jj = j < m ? j : m - 1;
-    const float inv_bw = 1.0f / bw;
-    const float lognorm = -0.5f * (float)d * LVAE_LOG_2PI;
-    const float scale = powf(bw, -(float)d);
-    float y0 = Y[jj * d];
-    float acc = 0.f;
-    for (int64_t i = 0; i < n; ++i) {
-        float q = 0.f;
-        if (d == 1) {
-            const float u = (X[i] - y0) * inv_bw;
-            q = u * u;
-        } else {
-            for (int dd = 0; dd < d; ++dd) {
-                const float u = (X[i * d + dd] - Y[jj * d + dd]) * inv_bw;
-                q += u * u;
+    const float s = sqrtf(0.5f * LVAE_LOG2E) / bw;
+    const float c0 = -0.5f * LVAE_LOG_2PI * LVAE_LOG2E - (ref ? ref[jj] : 0.f);
+    const f32x2 y2 = {Y[jj], Y[jj]}, s2 = {s, s}, c2 = {c0, c0};
+    const int64_t i0 = (int64_t)blockIdx.y * rows_per_split;      // multiple of 8
+    int64_t i1 = i0 + rows_per_split;
+    if (i1 > n) i1 = n;
+    f32x2 acc = MAXPASS ? (f32x2){-INFINITY, -INFINITY} : (f32x2){0.f, 0.f};
+    int64_t i = i0;
+    for (; i + 8 <= i1; i += 8) {
+        const f32x2* __restrict__ xp = reinterpret_cast<const f32x2*>(X + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x2 u = (xp[k] - y2) * s2;
+            const f32x2 t = __builtin_elementwise_fma(-u, u, c2);
+            if (MAXPASS) {
+                acc.x = fmaxf(acc.x, t.x);
+                acc.y = fmaxf(acc.y, t.y);
+            } else {
+                f32x2 e;
+                e.x = lvae_exp2(t.x);
+                e.y = lvae_exp2(t.y);
+                acc += e;
             }
         }
-        acc += scale * expf(-0.5f * q + lognorm);
     }
-    if (j < m) out[j] = logf(acc / (float)n);
+    float a = MAXPASS ? fmaxf(acc.x, acc.y) : acc.x + acc.y;
+    for (; i < i1; ++i) {
+        const float u = (X[i] - y2.x) * s;
+        const float t = fmaf(-u, u, c0);
+        a = MAXPASS ? fmaxf(a, t) : a + lvae_exp2(t);
+    }
+    if (j < m) partial[(int64_t)blockIdx.y * m + j] = a;
 }
 
-int lvae_launch_kde(const float* X, const float* Y, int64_t n, int64_t m, int d, float bw, float* out,
-                    hipStream_t st) {
-    hipLaunchKernelGGL(kde_score_kernel, dim3((unsigned)lvae_ceil_div(m, 256)), dim3(256), 0, st, X, Y, n, m,
-                       d, bw, out);
+// Any d: one exponential per pair.
+template <bool MAXPASS>
+__global__ void __launch_bounds__(256)
+kde_nd_kernel(const float* __restrict__ X, const float* __restrict__ Y, int64_t n, int64_t m, int d, float bw,
+              int64_t rows_per_split, const float* __restrict__ ref, float* __restrict__ partial) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t jj = j < m ? j : m - 1;
+    const float s = sqrtf(0.5f * LVAE_LOG2E) / bw;
+    const float c0 = -0.5f * (float)d * LVAE_LOG_2PI * LVAE_LOG2E - (ref ? ref[jj] : 0.f);
+    const int64_t i0 = (int64_t)blockIdx.y * rows_per_split;
+    int64_t i1 = i0 + rows_per_split;
+    if (i1 > n) i1 = n;
+    float a = MAXPASS ? -INFINITY : 0.f;
+    for (int64_t i = i0; i < i1; ++i) {
+        float t = c0;
+        for (int dd = 0; dd < d; ++dd) {
+            const float u = (X[i * d + dd] - Y[jj * d + dd]) * s;
+            t = fmaf(-u, u, t);
+        }
+        a = MAXPASS ? fmaxf(a, t) : a + lvae_exp2(t);
+    }
+    if (j < m) partial[(int64_t)blockIdx.y * m + j] = a;
+}
+
+// mode 0: ref[j] = max_k partial[k][j] - c0   (the exponent maximum without the constant, for the second pass)
+// mode 1: out[j] = ln( bw^-d * sum_k partial[k][j] / n ) (+ ref[j] ln2 when stabilised)
+__global__ void __launch_bounds__(256)
+kde_finalize_kernel(const float* __restrict__ partial, int nsplit, int64_t m, int mode, float log_scale_over_n,
+                    float c0, const float* __restrict__ ref_in, float* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    if (mode == 0) {
+        float mx = -INFINITY;
+        for (int k = 0; k < nsplit; ++k) mx = fmaxf(mx, partial[(int64_t)k * m + j]);
+        out[j] = mx - c0;
+    } else {
+        double sacc = 0.0;
+        for (int k = 0; k < nsplit; ++k) sacc += (double)partial[(int64_t)k * m + j];
+        const float sum32 = (float)sacc;
+        out[j] = logf(sum32) + log_scale_over_n + (ref_in ? ref_in[j] * (float)LVAE_LN2 : 0.f);
+    }
+}
+
+static int kde_pass(bool maxpass, const float* X, const float* Y, int64_t n, int64_t m, int d, float bw,
+                    int nsplit, int64_t rows, const float* ref, float* partial, hipStream_t st) {
+    const dim3 grid((unsigned)lvae_ceil_div(m, 256), (unsigned)nsplit);
+    if (d == 1) {
+        if (maxpass) hipLaunchKernelGGL(kde_1d_kernel<true>, grid, dim3(256), 0, st, X, Y, n, m, bw, rows, ref, partial);
+        else hipLaunchKernelGGL(kde_1d_kernel<false>, grid, dim3(256), 0, st, X, Y, n, m, bw, rows, ref, partial);
+    } else {
+        if (maxpass) hipLaunchKernelGGL(kde_nd_kernel<true>, grid, dim3(256), 0, st, X, Y, n, m, d, bw, rows, ref, partial);
+        else hipLaunchKernelGGL(kde_nd_kernel<false>, grid, dim3(256), 0, st, X, Y, n, m, d, bw, rows, ref, partial);
+    }
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+// workspace: partial [nsplit][m] floats + ref [m] floats
+void lvae_kde_plan(int64_t n, int64_t m, int* nsplit, int64_t* rows) {
+    const int64_t waves = lvae_ceil_div(m, 64);
+    int64_t ns = lvae_ceil_div(4096, waves);
+    const int64_t cap = lvae_ceil_div(n, 64);
+    if (ns > cap) ns = cap;
+    if (ns > 64) ns = 64;
+    if (ns < 1) ns = 1;
+    int64_t r = lvae_round_up(lvae_ceil_div(n, ns), 8);
+    *rows = r;
+    *nsplit = (int)lvae_ceil_div(n, r);
+}
+
+int lvae_launch_kde(const float* X, const float* Y, int64_t n, int64_t m, int d, float bw, int stabilise,
+                    float* out, float* ws, hipStream_t st) {
+    int nsplit;
+    int64_t rows;
+    lvae_kde_plan(n, m, &nsplit, &rows);
+    float* partial = ws;
+    float* ref = ws + (size_t)nsplit * m;
+    const float c0 = -0.5f * (float)d * LVAE_LOG_2PI * LVAE_LOG2E;
+    const float log_scale_over_n = -(float)d * logf(bw) - logf((float)n);
+    int rc;
+    if (stabilise) {
+        rc = kde_pass(true, X, Y, n, m, d, bw, nsplit, rows, nullptr, partial, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kde_finalize_kernel, dim3((unsigned)lvae_ceil_div(m, 256)), dim3(256), 0, st, partial,
+                           nsplit, m, 0, 0.f, c0, nullptr, ref);
+        LVAE_LAUNCH_CHECK();
+    }
+    rc = kde_pass(false, X, Y, n, m, d, bw, nsplit, rows, stabilise ? ref : nullptr, partial, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kde_finalize_kernel, dim3((unsigned)lvae_ceil_div(m, 256)), dim3(256), 0, st, partial,
+                       nsplit, m, 1, log_scale_over_n, c0, stabilise ? ref : nullptr, out);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }

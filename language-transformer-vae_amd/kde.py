@@ -17,9 +17,9 @@ class GaussianKDE:
         self.dims = X.shape[-1]
         self.n = X.shape[0]
 
-    def score_samples(self, Y, X=None):
+    def score_samples(self, Y, X=None, stabilise=False):
         """:33-60 -- log kernel density estimate of every row of Y [m, d]; unstabilised like the
-        reference (quirk Q6: -inf when every kernel term underflows)."""
+        reference (quirk Q6: -inf when every kernel term underflows) unless ``stabilise`` is set."""
         if X is None:
             X = self.X
         Xc, Yc = N.as_f32(X, "X"), N.as_f32(Y, "Y")
@@ -28,6 +28,10 @@ class GaussianKDE:
         dev = Yc.device
         with torch.cuda.device(dev):
             out = torch.empty(Yc.shape[0], dtype=torch.float32, device=dev)
+            nbytes = N._i64(0)
+            N.check(N.lib().lvae_kde_workspace_bytes(Xc.shape[0], Yc.shape[0], nbytes))
+            ws = N.workspace(nbytes.value, dev)
             N.check(N.lib().lvae_kde_score_f32(N.ptr(Xc), N.ptr(Yc), Xc.shape[0], Yc.shape[0], Xc.shape[1],
-                                               float(self.bw), N.ptr(out), N.stream_ptr(dev)))
+                                               float(self.bw), int(bool(stabilise)), N.ptr(out), N.ptr(ws),
+                                               nbytes.value, N.stream_ptr(dev)))
         return out

@@ -57,7 +57,7 @@ def test_argument_validation_and_error_text():
     assert rc == -1
     rc = lib.lvae_reparam_iw_f32(None, None, None, None, 4, 4, 32, None, None, None, None, None)
     assert rc == -1 and b"non-NULL" in lib.lvae_last_error()
-    rc = lib.lvae_kde_score_f32(None, None, 4, 4, 1, 1.0, None, None)
+    rc = lib.lvae_kde_score_f32(None, None, 4, 4, 1, 1.0, 0, None, None, 0, None)
     assert rc == -1
     dummy = ctypes.c_void_p(256)
     arr = (ctypes.c_float * 2)(0.1, -1.0)
