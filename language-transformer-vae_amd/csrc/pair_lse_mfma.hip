@@ -158,17 +158,21 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
 
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
+    // global addresses = wave-uniform base (scalar registers) + a constant 32-bit lane offset, so that the
+    // per-chunk address arithmetic stays on the scalar unit
+    const unsigned lane16 = (unsigned)lane * 16u, lane4 = (unsigned)lane * 4u;
     auto dma_chunk = [&](int64_t blk, int ch, int stage) {
-        const float* g = rfrag + (blk * (DP / 4) + ch * CQ) * 256 + lane * 4;
+        const char* g = reinterpret_cast<const char*>(rfrag + (blk * (DP / 4) + ch * CQ) * 256);
         float* l = ring + stage * STAGE_F;
 #pragma unroll
         for (int q0 = 0; q0 < CQ; q0 += 4) {
             const int q = q0 + wave_u;
-            __builtin_amdgcn_global_load_lds((gptr_t)(g + q * 256), (lptr_t)(l + q * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(g + q * 1024 + lane16), (lptr_t)(l + q * 256), 16, 0, 0);
         }
         if (ch == 0) { // 64 lanes x 4 B: this block's 32 biases (+32 of the next block, unused); every wave
                        // writes the same bytes so that all waves have the same DMA count per chunk
-            __builtin_amdgcn_global_load_lds((gptr_t)(rbias + blk * 32 + lane), (lptr_t)(l + CHUNK_F), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(rbias + blk * 32) + lane4),
+                                             (lptr_t)(l + CHUNK_F), 4, 0, 0);
             if (PERM) {
                 const float* lg = reinterpret_cast<const float*>(pa.labfrag) + blk * LAB_F + lane * 4;
                 float* ll = lring + (int)((blk - b0) % NSTL) * LAB_F;
@@ -182,10 +186,10 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     };
     // chunk index t (counted from this workgroup's first block) -> (block, chunk-in-block), clamped to
     // the last chunk of the range so that running ahead past the end is a harmless re-read
-    const int64_t t_end = (b1 - b0) * CPB;
-    auto dma_linear = [&](int64_t t) {
+    const int t_end = (int)(b1 - b0) * CPB;              // < 2^31: a split holds at most 2^26 blocks
+    auto dma_linear = [&](int t) {
         if (t >= t_end) t = t_end - 1;
-        dma_chunk(b0 + t / CPB, (int)(t % CPB), (int)(t % NST));
+        dma_chunk(b0 + t / CPB, t % CPB, t % NST);
     };
 
     auto mask_diag = [&](f32x16 (&acc)[NCB], int64_t blk) {
@@ -429,14 +433,14 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     // One block: keep the ring one chunk ahead, run the DP*NCB MFMAs into `acc` (first step takes the
     // row biases as its C operand) while the epilogue of `prev` issues in their shadow.  Everything is
     // pinned in program order (sched_barrier) so the compiler cannot bunch the epilogue up.
-    int64_t t_lin = 0;                                     // chunks consumed so far by this wave
+    int t_lin = 0;                                         // chunks consumed so far by this wave
     auto run_block = [&](f32x16 (&acc)[NCB], const f32x16 (&prev)[NCB], int64_t blk, bool with_epi) {
         const f32x16 cv = c_pre;
         if (EPI >= 1 && EPI <= 3) set_weights(blk - 1);
 #pragma unroll
         for (int ch = 0; ch < CPB; ++ch) {
-            const int stage = (int)(t_lin % NST);
-            const int stage_next = (int)((t_lin + 1) % NST);
+            const int stage = t_lin % NST;
+            const int stage_next = (t_lin + 1) % NST;
 #ifndef LVAE_DBG_NODMA
             dma_linear(t_lin + PF);    // into the stage consumed one chunk ago (freed by the last barrier)
 #endif
