@@ -267,13 +267,8 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
             // fixed reference (folded into the row biases by lse_shift_bias_kernel): every term is at
             // most 2^LSE_HEADROOM, so the tile is two exponentials and one packed add per slice
             f32x2 e;
-#ifdef LVAE_DBG_NOEXP
-            e.x = prev[cb][2 * ms];
-            e.y = prev[cb][2 * ms + 1];
-#else
             e.x = lvae_exp2(prev[cb][2 * ms]);
             e.y = lvae_exp2(prev[cb][2 * ms + 1]);
-#endif
             kt2[cb] += e;
         } else if (EPI >= 1) {
             if (ms < 8) {
@@ -299,12 +294,8 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
             f32x2 x;    // (the compiler would split this packed add into two scalar ones)
             asm("v_pk_add_f32 %0, %1, %2" : "=v"(x) : "v"(pr), "v"(m2[cb]));
             f32x2 e;
-#ifdef LVAE_DBG_NOEXP
-            e = x;
-#else
             e.x = lvae_exp2(x.x);
             e.y = lvae_exp2(x.y);
-#endif
             if (ms == 0) kt2[cb] = e;
             else kt2[cb] += e;
         } else {
@@ -313,11 +304,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
             // Otherwise (the first tile, or a rare jump of the maximum; inf/NaN land here too) the whole
             // wave redoes the tile against the true maximum.
             const float ts = kt2[cb].x + kt2[cb].y;
-#ifdef LVAE_DBG_NOBRANCH
-            if (false) {
-#else
             if (__builtin_expect(__any(!(ts < LSE_BIG)), 0)) {
-#endif
                 float t = prev[cb][0];
 #pragma unroll
                 for (int e = 1; e < 16; ++e) t = fmaxf(t, prev[cb][e]);
@@ -441,7 +428,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
         for (int ch = 0; ch < CPB; ++ch) {
             const int stage = t_lin % NST;
             const int stage_next = (t_lin + 1) % NST;
-#ifndef LVAE_DBG_NODMA
+#ifndef LVAE_DBG_NODMA   // (ablation builds for DESIGN.md: -DLVAE_DBG_NODMA / -DLVAE_DBG_NOBAR; results are garbage)
             dma_linear(t_lin + PF);    // into the stage consumed one chunk ago (freed by the last barrier)
 #endif
             f32x4 a4[2];
@@ -467,13 +454,11 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
                         acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q & 1][e], bz[cb][st],
                                                                        st == 0 ? cv : acc[cb], 0, 0, 0);
                         const int u = st * NCB + cb;
-#ifndef LVAE_DBG_NOEPI
                         if (with_epi) {   // micro-slices spread evenly over the block's MFMA slots
 #pragma unroll
                             for (int k = (u * MS_TOTAL) / SLOTS; k < ((u + 1) * MS_TOTAL) / SLOTS; ++k)
                                 epi_micro(prev, k / EPI_MS, k % EPI_MS);
                         }
-#endif
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
