@@ -8,13 +8,17 @@
 // 32-row blocks of the reduced axis through an LDS ring shared by the workgroup's four waves and filled
 // by LDS-DMA (one 1 KiB piece per 4 MFMA steps, fragment-major layout), the accumulators start from the
 // row bias, DP chained MFMAs per 32x32 tile produce the base-2 log-densities, and the epilogue folds the
-// 16 values a lane holds (16 reduced rows of its own column) into that lane's running (max, sum).  The reduction axis lives on the MFMA ROW
-// index, i.e. in registers, so the logsumexp needs no cross-lane traffic until the very end, where
-// the two half-waves (rows +0..3 / +4..7 of every 8) are merged with one wave shuffle.
+// 16 values a lane holds (16 reduced rows of its own column) into that lane's sum.  The reduction axis
+// lives on the MFMA ROW index, i.e. in registers, so the logsumexp needs no cross-lane traffic until the
+// very end, where the two half-waves (rows +0..3 / +4..7 of every 8) are merged with one wave shuffle.
 //
-// The running max is updated lazily: a tile only triggers a rescale when its max exceeds the running
-// one by more than LSE_THR (base-2), so the common tile costs one v_exp_f32 per pair and nothing else
-// on the transcendental pipe; sums stay below 2^LSE_THR * R, far from fp32 overflow.
+// Two logsumexp epilogues (template parameter EPI):
+//   EPI 4  fixed reference: lse_shift_bias_kernel has folded -(largest density normaliser - 100) into the
+//          row biases, every term is <= 2^100, and a tile costs 16 v_exp_f32 + 8 v_pk_add_f32.  Columns
+//          whose total underflows are flagged by finalize_lse_kernel and redone with
+//   EPI 0  running maximum, updated lazily: the tile sum of exponentials relative to the running max
+//          proves (all terms are positive) that no term exceeded it by LSE_THR bits; otherwise the wave
+//          redoes the tile against the true maximum.  Sums stay below 2^LSE_THR * R.
 //
 // Bound: fp32 MFMA (157.3 TFLOP/s); algorithmic cost 4*D flop per pair.  HBM traffic is negligible
 // (operands are L2/Infinity-Cache resident and re-read by every wave).
@@ -41,12 +45,14 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 }
 #define LSE_MINIT (-1.0e30f)
 
-// EPI 0: streaming logsumexp (log q(z), q_z_estimate, MI bounds).
-// EPI 1: kernel-matrix column sums.  The contraction is the squared distance d2 = |x - y|^2 (POINT x
+// EPI 0 / 4: streaming logsumexp (log q(z), q_z_estimate, MI bounds), see above.
+// EPI 1-3: kernel-matrix column sums.  The contraction is the squared distance d2 = |x - y|^2 (POINT x
 //        SAMPLE operands) and every pair contributes f(d2) = sum_k exp(-alpha_k * (eps + |d2|)),
 //        accumulated per column in float64 (one tile's 16 terms are first summed in float32).
-//        poly mode: alpha_k = base * (integer), f is a polynomial in t = exp(-base*v) evaluated by
-//        Horner's rule (one v_exp_f32 per pair for any number of bandwidths).
+//        EPI 1: one bandwidth; EPI 2: alpha_k = base * (integer <= 16), f is a polynomial in
+//        t = exp(-base*v) evaluated by Horner's rule on the packed fp32 pipe (one v_exp_f32 per pair for
+//        any number of bandwidths); EPI 3: one exponential per bandwidth.
+//        sym: a sample against itself -- only the tiles on and above the diagonal are visited.
 // PERM (with EPI 1/2, NCB == 1): label-permutation sums for the MMD permutation test.  Every 32x32
 //        tile of kernel values K[r][c] is, straight from the accumulator layout, the A operand
 //        (i = column c, k = row r) of v_mfma_f32_32x32x16_bf16 against 0/1 label fragments
