@@ -210,10 +210,13 @@ int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int64_t n2, int
  * lvae_mmd_rbf_f32, optionally skipping the pairs j == i + diag_offset (exclude_diag != 0).  This is the
  * multi-GPU building block of the MMD (a = this rank's rows, b = the gathered sample, diag_offset = the
  * rank's first row; loss_and_optimisation.py:46-60,:617-619 evaluate the whole matrix in one process).
- * out_total: 1 float64 (may be NULL); out_colsum: [na] float64, the per-a_i sums over j (may be NULL). */
+ * out_total: 1 float64 (may be NULL); out_colsum: [na] float64, the per-a_i sums over j (may be NULL).
+ * symmetric != 0: a must be the rows diag_offset .. diag_offset+na-1 of b (diag_offset % 32 == 0); only the
+ * tiles on and above the diagonal are evaluated and counted twice where due, so that the totals of all owners
+ * still add up to the sum over the full symmetric matrix (out_colsum must be NULL). */
 int lvae_kernel_sum_workspace_bytes(int64_t na, int64_t nb, int D, int64_t* out_bytes);
 int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, int64_t nb, int D, const float* alphas,
-                        int n_alpha, float dist_eps, int exclude_diag, int64_t diag_offset,
+                        int n_alpha, float dist_eps, int exclude_diag, int64_t diag_offset, int symmetric,
                         double* out_total, double* out_colsum, void* ws, int64_t ws_bytes, void* stream);
 
 /* Label-permutation sums for the MMD permutation test (torch_two_sample MMDStatistic.pval; the C4

@@ -58,7 +58,7 @@ _SIGNATURES = {
                                 ctypes.c_void_p, ctypes.c_void_p, _i64, ctypes.c_void_p]),
     "lvae_kernel_sum_workspace_bytes": (_int, [_i64, _i64, _int, ctypes.POINTER(_i64)]),
     "lvae_kernel_sum_f32": (_int, [_c_f32p, _c_f32p, _i64, _i64, _int, ctypes.POINTER(_f32), _int, _f32, _int,
-                                   _i64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _i64,
+                                   _i64, _int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _i64,
                                    ctypes.c_void_p]),
     "lvae_log_qz_bwd_workspace_bytes": (_int, [_i64, _i64, _int, _int, ctypes.POINTER(_i64)]),
     "lvae_log_qz_bwd_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _i64, _int, _f32, _c_f32p, _c_f32p, _c_f32p,

@@ -775,26 +775,29 @@ extern "C" int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int6
 extern "C" int lvae_kernel_sum_workspace_bytes(int64_t na, int64_t nb, int D, int64_t* out_bytes) {
     LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
     LVAE_CHECK_ARG(na >= 1 && nb >= 1 && D >= 1, "need na, nb, D >= 1");
-    const PairPlan p = lvae_make_pair_plan(nb, na, D, false);
+    const PairPlan p = lvae_make_pair_plan(nb, na, D, false, 0, true);     // the finer (symmetric) plan is the larger
     *out_bytes = (int64_t)p.total;
     return LVAE_OK;
 }
 
 extern "C" int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, int64_t nb, int D,
                                    const float* alphas, int n_alpha, float dist_eps, int exclude_diag,
-                                   int64_t diag_offset, double* out_total, double* out_colsum, void* ws,
-                                   int64_t ws_bytes, void* stream) {
+                                   int64_t diag_offset, int symmetric, double* out_total, double* out_colsum,
+                                   void* ws, int64_t ws_bytes, void* stream) {
     LVAE_CHECK_ARG(a && b, "a and b must be non-NULL");
     LVAE_CHECK_ARG(out_total || out_colsum, "at least one of out_total / out_colsum is required");
     LVAE_CHECK_ARG(na >= 1 && nb >= 1, "need na, nb >= 1");
     LVAE_CHECK_ARG(D >= 1 && D <= 128, "the kernel-sum path needs 1 <= D <= 128 (got %d)", D);
     LVAE_CHECK_ARG(na < (1LL << 31) && nb < (1LL << 31), "na, nb must be below 2^31");
+    LVAE_CHECK_ARG(!symmetric || (diag_offset >= 0 && diag_offset % 32 == 0 && diag_offset + na <= nb && !out_colsum),
+                   "symmetric evaluation: a must be rows diag_offset.. of b, diag_offset %% 32 == 0, totals only");
     KsumParams kp;
     int zeros = 0;
     int rc = build_ksum(alphas, n_alpha, dist_eps, &kp, &zeros);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const PairPlan p = lvae_make_pair_plan(nb, na, D, false);
+    const int sym = symmetric != 0;
+    const PairPlan p = lvae_make_pair_plan(nb, na, D, false, 0, sym);
     rc = check_ws(ws, ws_bytes, p.total);
     if (rc) return rc;
     char* base = (char*)ws;
@@ -814,7 +817,7 @@ extern "C" int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, i
         if (rc) return rc;
         rc = lvae_launch_pair_mfma(p, (float*)(base + p.off_rfrag), (float*)(base + p.off_rbias),
                                    (float*)(base + p.off_cop), partial, hdr, -1.f, 0, exclude_diag != 0,
-                                   diag_offset, ksum_epi(kp), nullptr, 0, st);
+                                   diag_offset, ksum_epi(kp), nullptr, sym, st);
         if (rc) return rc;
     }
     return lvae_launch_ksum_columns((const double*)partial, p.nsplit, p.cpad, na, nb, exclude_diag != 0,

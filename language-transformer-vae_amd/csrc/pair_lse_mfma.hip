@@ -117,7 +117,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     // block only visits the row blocks from its own diagonal tile on (weight 1) and counts the tiles
     // beyond it twice; the workgroup starts at its first column block's diagonal tile.
     const bool use_sym = EPI >= 1 && EPI <= 3 && sym != 0;
-    const int64_t sym_off = PERM ? pa.col_offset / 32 : 0;    // block index of kept element 0 on the reduced axis
+    const int64_t sym_off = excl_offset / 32;    // block index of kept element 0 on the reduced axis (its diagonal)
     if (use_sym) {
         const int64_t gs = sym_off + (int64_t)blockIdx.x * 4 * NCB;
         if (b0 < gs) b0 = gs;
@@ -598,7 +598,8 @@ static int launch_t(const PairPlan& p, const float* rfrag, const float* rbias, c
 // the row biases; 1/2/3: kernel-matrix column sums (float64 partials; parameters in hdr->ksum: single
 // bandwidth / polynomial of degree <= 16 / arbitrary bandwidths).
 // redo_flags (may be NULL): one int per workgroup column group; workgroups whose flag is 0 exit.
-// sym != 0 (epi 1/2/3 only, kept and reduced operands built from the same sample): visit the upper
+// sym != 0 (epi 1/2/3 only; the kept elements are rows excl_offset.. of the reduced sample, excl_offset a
+// multiple of 32): visit the upper
 // triangle of tiles only; the TOTAL over columns is that of the full matrix, the per-column sums are not.
 int lvae_launch_pair_mfma(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                           float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,

@@ -145,28 +145,35 @@ def sharded_iw_log_p_x(mu_local, logvar_local, eps_local, log_p_x_z_local, group
     return out.reshape(-1)
 
 
-def hip_kernel_sum(a, b, alphas, dist_eps, exclude_diag, diag_offset):
+def hip_kernel_sum(a, b, alphas, dist_eps, exclude_diag, diag_offset, symmetric=False):
     """Per-rank compute of sharded_mmd on the HIP path: float64 device scalar."""
     from . import estimators as E
-    return E.kernel_sum(a, b, alphas, dist_eps, exclude_diag, diag_offset)
+    return E.kernel_sum(a, b, alphas, dist_eps, exclude_diag, diag_offset, symmetric=symmetric)
 
 
 def sharded_mmd(x_local, y_local, alphas, dist_eps=0.0, unbiased=False, group=None,
                 kernel_sum=hip_kernel_sum):
     """Gaussian-kernel MMD between two samples whose rows are sharded over ranks (the samples
     are replicated by all-gather, the kernel-matrix rows are partitioned, three float64 block sums are
-    all-reduced).  ``unbiased=True``, ``dist_eps=1e-5`` is the torch-two-sample statistic used at
+    all-reduced).  After the gather the compute partition is free: for the two self-terms every rank
+    evaluates two mirrored column chunks of the upper triangle (``mirrored_chunks``: half the work,
+    balanced over ranks); for the cross term it keeps its own rows of x against all of y.
+    ``unbiased=True``, ``dist_eps=1e-5`` is the torch-two-sample statistic used at
     loss_and_optimisation.py:617-619 (diagonals excluded, 1/(n(n-1)) weights); ``unbiased=False``,
     ``dist_eps=0``, ``alphas=[1/D^2]`` is maximum_mean_discrepancy (:46-60).  Returns a dict of Python
     floats, identical on every rank."""
     x_all, xoff = all_gather_rows(x_local.contiguous(), group)
     y_all, yoff = all_gather_rows(y_local.contiguous(), group)
-    rank = dist.get_rank(group)
-    sums = torch.stack([
-        kernel_sum(x_local, x_all, alphas, dist_eps, unbiased, xoff[rank]).reshape(()),
-        kernel_sum(y_local, y_all, alphas, dist_eps, unbiased, yoff[rank]).reshape(()),
-        kernel_sum(x_local, y_all, alphas, dist_eps, False, 0).reshape(()),
-    ]).to(torch.float64)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    parts = []
+    for full in (x_all, y_all):
+        acc = torch.zeros((), dtype=torch.float64, device=full.device)
+        for lo, hi in mirrored_chunks(full.shape[0], world, rank):
+            acc = acc + kernel_sum(full[lo:hi].contiguous(), full, alphas, dist_eps, unbiased, lo, True).reshape(())
+        parts.append(acc)
+    parts.append(kernel_sum(x_local, y_all, alphas, dist_eps, False, 0, False).reshape(())
+                 if x_local.shape[0] else torch.zeros((), dtype=torch.float64, device=x_all.device))
+    sums = torch.stack(parts).to(torch.float64)
     _all_reduce(sums, dist.ReduceOp.SUM, group)
     sxx, syy, sxy = sums.tolist()
     n1, n2 = float(x_all.shape[0]), float(y_all.shape[0])

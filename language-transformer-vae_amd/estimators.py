@@ -314,11 +314,13 @@ def mmd_rbf(x, y, alphas, dist_eps, unbiased):
     return out
 
 
-def kernel_sum(a, b, alphas, dist_eps, exclude_diag=False, diag_offset=0, colsum=False):
+def kernel_sum(a, b, alphas, dist_eps, exclude_diag=False, diag_offset=0, colsum=False, symmetric=False):
     """sum_{i,j} k(a_i, b_j) with k = sum_alpha exp(-alpha (dist_eps + |a_i - b_j|^2)), optionally
     without the pairs j == i + diag_offset: one block of the MMD's kernel-matrix sums (the multi-GPU
     building block; the matrix is never materialised).  Returns a float64 device scalar, and with
-    ``colsum`` also the [na] float64 per-row-of-a sums."""
+    ``colsum`` also the [na] float64 per-row-of-a sums.  ``symmetric``: ``a`` is rows diag_offset.. of ``b``
+    (a multiple of 32) and only the upper triangle of tiles is evaluated; the totals of all owners still add
+    up to the full sum."""
     a, b = N.as_f32(a, "a"), N.as_f32(b, "b")
     if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1]:
         raise ValueError("a and b must be [na, D] and [nb, D]")
@@ -332,7 +334,8 @@ def kernel_sum(a, b, alphas, dist_eps, exclude_diag=False, diag_offset=0, colsum
         total = torch.empty(1, dtype=torch.float64, device=dev)
         cs = torch.empty(na, dtype=torch.float64, device=dev) if colsum else None
         N.check(N.lib().lvae_kernel_sum_f32(N.ptr(a), N.ptr(b), na, nb, D, arr, nalpha, float(dist_eps),
-                                            int(bool(exclude_diag)), int(diag_offset), N.ptr(total),
+                                            int(bool(exclude_diag)), int(diag_offset), int(bool(symmetric)),
+                                            N.ptr(total),
                                             N.ptr(cs), N.ptr(ws), nbytes.value, N.stream_ptr(dev)))
     return (total[0], cs) if colsum else total[0]
 

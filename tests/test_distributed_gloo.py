@@ -103,15 +103,20 @@ def test_sharded_latent_stats_world2(ragged):
     assert results[0][1] == results[1][1]      # identical on every rank
 
 
-def _oracle_kernel_sum(a, b, alphas, dist_eps, exclude_diag, diag_offset):
+def _oracle_kernel_sum(a, b, alphas, dist_eps, exclude_diag, diag_offset, symmetric=False):
     a64, b64 = a.numpy().astype(np.float64), b.numpy().astype(np.float64)
     d2 = dist_eps + np.abs((a64 ** 2).sum(1)[:, None] + (b64 ** 2).sum(1)[None] - 2.0 * a64 @ b64.T)
     K = sum(np.exp(-al * d2) for al in alphas)
+    i = np.arange(a64.shape[0])
     if exclude_diag:
-        i = np.arange(a64.shape[0])
         j = i + diag_offset
         ok = (j >= 0) & (j < b64.shape[0])
         K[i[ok], j[ok]] = 0.0
+    if symmetric:      # tiles on (weight 1) and above (weight 2) the diagonal, as include/lvae.h describes
+        assert diag_offset % 32 == 0
+        cb = (diag_offset + i) // 32
+        rb = np.arange(b64.shape[0]) // 32
+        K = K * (2.0 * (rb[None, :] > cb[:, None]) + 1.0 * (rb[None, :] == cb[:, None]))
     return torch.tensor(K.sum(), dtype=torch.float64)
 
 
@@ -138,7 +143,7 @@ def _mmd_worker(rank, world, port, n1, n2, D, q):
 
 def test_sharded_mmd_world2():
     from oracle import oracle_np as onp
-    n1, n2, D, world = 70, 53, 8, 2
+    n1, n2, D, world = 170, 153, 8, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

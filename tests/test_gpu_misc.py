@@ -216,6 +216,20 @@ def test_kernel_sum_blocks(na, nb, D, off):
             np.testing.assert_allclose(cs.cpu().numpy(), Kx.sum(1), rtol=1e-5)
             tot2 = E.kernel_sum(dev(a), dev(b), alphas, eps, excl, off)
             assert float(tot2) == float(tot)
+    # symmetric evaluation: mirrored 32-aligned chunks of one sample against itself add up to the full sum
+    from lvae.distributed import mirrored_chunks
+    alphas = [0.1 * i for i in range(15)]
+    b64 = b.astype(np.float64)
+    d2 = 1e-5 + np.abs((b64 ** 2).sum(1)[:, None] + (b64 ** 2).sum(1)[None] - 2.0 * b64 @ b64.T)
+    K = sum(np.exp(-al * d2) for al in alphas)
+    for excl in (False, True):
+        want = K.sum() - (np.trace(K) if excl else 0.0)
+        acc = 0.0
+        for rank in range(3):
+            for lo, hi in mirrored_chunks(nb, 3, rank):
+                acc += float(E.kernel_sum(dev(b[lo:hi]), dev(b), alphas, 1e-5, excl, lo, symmetric=True))
+        # (with the diagonal included, the self-pairs' d2 = |x|^2 - 2 x.x + |x|^2 is fp32 rounding noise, not 0)
+        assert abs(acc - want) <= (2e-6 if excl else 2e-5) * want, excl
 
 
 @pytest.mark.parametrize("n1,n2,D,P", [(300, 340, 32, 20), (257, 190, 64, 130), (1000, 1500, 16, 9),
