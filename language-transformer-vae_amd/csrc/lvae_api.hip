@@ -11,7 +11,8 @@ int lvae_launch_prep(int src, bool frag, const float* x, const float* spread, in
                      int64_t n, int64_t npad, int D, int DP, PairHeader* hdr, int64_t ngauss,
                      float* out, float* bias, float* dparams, int DC, hipStream_t st);
 int lvae_launch_prep_dparams(const float* mu, const float* spread, int spread_kind, int64_t n, int D,
-                             int DC, float* dparams, hipStream_t st);
+                             int DC, float* dparams, const PairHeader* gate_hdr, float cond_limit,
+                             hipStream_t st);
 int lvae_launch_finalize(const float2* partial, int nsplit, int64_t cpad, int64_t C,
                          const float* colbias, float log_norm, float* out, float* out_max,
                          float* out_sum, const PairHeader* hdr, float cond_limit, int use_if_above,
@@ -235,20 +236,30 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     const bool need_mfma = want_joint && joint_path != LVAE_PATH_DIRECT;
     const bool need_direct = with_pm || (want_joint && joint_path != LVAE_PATH_MFMA);
 
+    // Direct-form parameters (25 MB at C2) are only written when something will read them: always with
+    // prod-marginals or a forced direct path; in AUTO mode by a separate kernel that runs iff the device-side
+    // conditioning test selects the direct path.
+    const bool auto_gate = want_joint && joint_path == LVAE_PATH_AUTO;
+    const bool dparams_now = with_pm || (want_joint && joint_path == LVAE_PATH_DIRECT);
     LVAE_HIP(hipMemsetAsync(hdr, 0, sizeof(PairHeader), st));
     if (p.DP) {
         rc = lvae_launch_colsum(mu, N, D, hdr, st);
         if (rc) return rc;
         rc = lvae_launch_prep(0, true, mu, spread, spread_kind, N, p.nblk * 32, D, p.DP, hdr, N,
-                              rfrag, rbias, need_direct ? dparams : nullptr, p.DC, st);
+                              rfrag, rbias, dparams_now ? dparams : nullptr, p.DC, st);
         if (rc) return rc;
+        if (need_direct && !dparams_now) {
+            rc = lvae_launch_prep_dparams(mu, spread, spread_kind, N, D, p.DC, dparams,
+                                          auto_gate ? hdr : nullptr, LVAE_COND_LIMIT, st);
+            if (rc) return rc;
+        }
         if (need_mfma) {
             rc = lvae_launch_prep(1, false, z, nullptr, 0, M, p.cpad, D, p.DP, hdr, N, cop, nullptr,
                                   nullptr, p.DC, st);
             if (rc) return rc;
         }
     } else {
-        rc = lvae_launch_prep_dparams(mu, spread, spread_kind, N, D, p.DC, dparams, st);
+        rc = lvae_launch_prep_dparams(mu, spread, spread_kind, N, D, p.DC, dparams, nullptr, 0.f, st);
         if (rc) return rc;
     }
 
@@ -425,7 +436,7 @@ extern "C" int lvae_log_qz_bwd_f32(const float* z, const float* mu, const float*
     float* rec = (float*)(base + g.off_rec);
     float* pdz = (float*)(base + g.off_pdz);
     float* pdp = (float*)(base + g.off_pdp);
-    rc = lvae_launch_prep_dparams(mu, logvar, LVAE_SPREAD_LOGVAR, N, D, p.DC, dparams, st);
+    rc = lvae_launch_prep_dparams(mu, logvar, LVAE_SPREAD_LOGVAR, N, D, p.DC, dparams, nullptr, 0.f, st);
     if (rc) return rc;
     if (pm) {   // per-(sample, dimension) logsumexp over the posteriors: the forward prod-marginals sweep
         rc = lvae_launch_pair_direct(p, false, true, z, dparams, nullptr, (float2*)(base + p.off_dpartial_pm),

@@ -145,19 +145,36 @@ prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ sprea
                 if (!valid) b = FRAG ? (POINT ? INFINITY : -INFINITY) : 0.f;
                 bias[row] = b;
             }
-            if (GAUSS && valid) {
+            if (GAUSS && !FRAG && valid) {
                 atomicMax(&hdr->cond_bits, __float_as_uint(k));
-                // the density's normaliser bounds every term of row `row`: v_ij <= -0.5 log2e sum_d log(2 pi var)
                 atomicMax(&hdr->cmax_key, lvae_float_key(-0.5f * LVAE_LOG2E * nn));
+            }
+            if (GAUSS && FRAG) {
+                // the density's normaliser bounds every term of row `row`: v_ij <= -0.5 log2e sum_d log(2 pi var).
+                // FRAG: the 32 row threads are lanes 0..31 of wave 0 -> one pair of atomics per block
+                unsigned kb = valid ? __float_as_uint(k) : 0u;
+                unsigned nk = valid ? lvae_float_key(-0.5f * LVAE_LOG2E * nn) : 0u;
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) {
+                    kb = max(kb, (unsigned)__shfl_xor((int)kb, off, 64));
+                    nk = max(nk, (unsigned)__shfl_xor((int)nk, off, 64));
+                }
+                if (r == 0) {
+                    atomicMax(&hdr->cond_bits, kb);
+                    atomicMax(&hdr->cmax_key, nk);
+                }
             }
         }
     }
 }
 
 // Direct-path parameters only (used when the MFMA path is not available for this D).
+// gate_hdr != NULL: only when the conditioning estimate selects the direct path (cond > cond_limit).
 __global__ void prep_dparams_kernel(const float* __restrict__ mu, const float* __restrict__ spread,
                                     int spread_kind, int64_t n, int D, int DC,
-                                    float* __restrict__ dparams) {
+                                    float* __restrict__ dparams, const PairHeader* __restrict__ gate_hdr,
+                                    float cond_limit) {
+    if (gate_hdr && !(__uint_as_float(gate_hdr->cond_bits) > cond_limit)) return;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * DC) return;
     const int64_t row = idx / DC;
@@ -272,10 +289,11 @@ int lvae_launch_prep(int src, bool frag, const float* x, const float* spread, in
 }
 
 int lvae_launch_prep_dparams(const float* mu, const float* spread, int spread_kind, int64_t n, int D,
-                             int DC, float* dparams, hipStream_t st) {
+                             int DC, float* dparams, const PairHeader* gate_hdr, float cond_limit,
+                             hipStream_t st) {
     const int64_t total = n * DC;
     hipLaunchKernelGGL(prep_dparams_kernel, dim3((unsigned)lvae_ceil_div(total, 256)), dim3(256), 0,
-                       st, mu, spread, spread_kind, n, D, DC, dparams);
+                       st, mu, spread, spread_kind, n, D, DC, dparams, gate_hdr, cond_limit);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }
