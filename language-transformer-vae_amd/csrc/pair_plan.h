@@ -102,14 +102,23 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
     if (ns < 1) ns = 1;
     p.blk_per_split = lvae_ceil_div(p.nblk, ns);
     p.nsplit = (int)lvae_ceil_div(p.nblk, p.blk_per_split);
-    // direct grid: one lane per kept element, 64 per wave
-    const int64_t dwaves = p.cpad / 64;
-    int64_t ds = lvae_ceil_div(4096, dwaves);
-    if (ds > lvae_ceil_div(R, 64)) ds = lvae_ceil_div(R, 64);
-    if (ds < 1) ds = 1;
-    if (ds > 64) ds = 64;
-    p.rows_per_dsplit = lvae_ceil_div(R, ds);
-    p.dsplit = (int)lvae_ceil_div(R, p.rows_per_dsplit);
+    // direct grid: one lane per kept element, 256 per workgroup, (cpad / 256) x dsplit equal workgroups, about
+    // six of them resident per CU (1536 on the chip).  Measured with the prod-marginals kernel: three rounds
+    // of workgroups beat one by 9 % on large problems, while on small ones every extra split costs more in
+    // partials (dsplit x cpad x DC x 8 B, written and merged) than it gains: aim at 4608 / 1536 / 768
+    // workgroups by size, never fewer than 128 reduced rows per split.
+    {
+        const int64_t dgroups = p.cpad / 256 > 0 ? p.cpad / 256 : 1;
+        const int64_t target = dgroups >= 192 ? 4608 : (dgroups >= 96 ? 1536 : 768);
+        int64_t ds = lvae_ceil_div(target, dgroups);
+        const char* ds_env = getenv("LVAE_DSPLIT");
+        if (ds_env) ds = atoll(ds_env);
+        if (ds > R / 128) ds = R / 128;
+        if (ds > 64) ds = 64;
+        if (ds < 1) ds = 1;
+        p.rows_per_dsplit = lvae_ceil_div(R, ds);
+        p.dsplit = (int)lvae_ceil_div(R, p.rows_per_dsplit);
+    }
     p.DC = D <= 16 ? 16 : (D <= 32 ? 32 : (D <= 64 ? 64 : (int)lvae_round_up(D, 16)));
 
     size_t o = 0;
