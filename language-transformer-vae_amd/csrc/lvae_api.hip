@@ -19,7 +19,7 @@ int lvae_launch_finalize(const float2* partial, int nsplit, int64_t cpad, int64_
                          int use_ref, int* flags_out, const int* flags_in, int group_cols, hipStream_t st);
 int lvae_launch_lse_shift_bias(float* rbias, int64_t n, PairHeader* hdr, hipStream_t st);
 int lvae_launch_finalize_pm(const float2* partial, int nsplit, int64_t cpad, int64_t C, int D, int DC,
-                            float log_norm, float* out, hipStream_t st);
+                            float log_norm, float* tmp, float* out, hipStream_t st);
 int lvae_launch_pair_lse_mfma(const PairPlan& p, const float* rfrag, const float* rbias,
                               const float* cop, float2* partial, const PairHeader* hdr,
                               float cond_limit, int use_if_above, bool excl, int64_t excl_offset,
@@ -316,7 +316,8 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
         }
     }
     if (with_pm) {
-        rc = lvae_launch_finalize_pm(dpartial_pm, p.dsplit, p.cpad, M, D, p.DC, log_norm, log_qz_pm, st);
+        rc = lvae_launch_finalize_pm(dpartial_pm, p.dsplit, p.cpad, M, D, p.DC, log_norm,
+                                     (float*)(base + p.off_pmtmp), log_qz_pm, st);
         if (rc) return rc;
     }
     return LVAE_OK;

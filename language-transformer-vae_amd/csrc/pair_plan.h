@@ -56,7 +56,7 @@ struct PairPlan {
     int DC;          // padded dim of the direct-path parameters: 16/32/64, or a multiple of 16 above
     // byte offsets into the workspace
     size_t off_hdr, off_rfrag, off_rbias, off_cop, off_colbias, off_partial;
-    size_t off_dparams, off_dpartial, off_dpartial_pm, off_dflags, off_redo, total;
+    size_t off_dparams, off_dpartial, off_dpartial_pm, off_dflags, off_pmtmp, off_redo, total;
 };
 
 static inline size_t lvae_align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -134,6 +134,8 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
     if (with_pm) o = lvae_align256(o + (size_t)p.dsplit * p.cpad * p.DC * 2 * sizeof(float));
     p.off_dflags = o;   // redo flags of the prod-marginals fast pass: [dsplit][DC/16][cpad/64]
     if (with_pm) o = lvae_align256(o + (size_t)p.dsplit * (p.DC / 16) * (p.cpad / 64) * sizeof(int));
+    p.off_pmtmp = o;    // prod-marginals: per-(dimension, kept element) log-terms before the sum over dimensions
+    if (with_pm) o = lvae_align256(o + (size_t)p.DC * p.cpad * sizeof(float));
     p.off_redo = o;     // redo flags of the fixed-reference logsumexp pass: one int per MFMA workgroup column group
     o = lvae_align256(o + (size_t)(p.cpad / 128 + 1) * sizeof(int));
     p.total = o;

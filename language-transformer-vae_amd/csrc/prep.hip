@@ -239,23 +239,37 @@ __global__ void finalize_lse_kernel(const float2* __restrict__ partial, int nspl
     }
 }
 
-// Same for the product-of-marginals partials [dsplit][DC][cpad]:
-//   out[i] = sum_{d<D} ( ln2 * (M_d + log2 S_d) - log_norm )
-__global__ void finalize_pm_kernel(const float2* __restrict__ partial, int nsplit, int64_t cpad,
-                                   int64_t C, int D, int DC, float log_norm, float* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// Same for the product-of-marginals partials [dsplit][DC][cpad], in two steps so that the merge runs on
+// D x C threads: (1) one thread per (dimension, kept element) merges the splits in one pass (running
+// maximum; the fast pass's partials all carry the reference 0) -> tmp[d][i] = ln2 (M + log2 S) - log_norm;
+// (2) out[i] = sum_{d<D} tmp[d][i], in order.
+__global__ void __launch_bounds__(256)
+finalize_pm_terms_kernel(const float2* __restrict__ partial, int nsplit, int64_t cpad, int64_t C, int DC,
+                         float log_norm, float* __restrict__ tmp) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int d = blockIdx.y;
+    if (i >= C) return;
+    float mx = -INFINITY;
+    double s = 0.0;
+    for (int k = 0; k < nsplit; ++k) {
+        const float2 p = partial[((int64_t)k * DC + d) * cpad + i];
+        if (p.y > 0.f) {
+            if (p.x > mx) {
+                s *= (double)lvae_exp2(mx - p.x);      // exp2(-inf) = 0 the first time
+                mx = p.x;
+            }
+            s += (double)p.y * (double)lvae_exp2(p.x - mx);
+        }
+    }
+    tmp[(int64_t)d * cpad + i] = (float)(((double)mx + log2(s)) * LVAE_LN2 - (double)log_norm);
+}
+
+__global__ void __launch_bounds__(256)
+finalize_pm_sum_kernel(const float* __restrict__ tmp, int64_t cpad, int64_t C, int D, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= C) return;
     double total = 0.0;
-    for (int d = 0; d < D; ++d) {
-        float mx = -INFINITY;
-        for (int k = 0; k < nsplit; ++k) mx = fmaxf(mx, partial[((int64_t)k * DC + d) * cpad + i].x);
-        double s = 0.0;
-        for (int k = 0; k < nsplit; ++k) {
-            const float2 p = partial[((int64_t)k * DC + d) * cpad + i];
-            if (p.y > 0.f) s += (double)p.y * exp2((double)p.x - (double)mx);
-        }
-        total += ((double)mx + log2(s)) * LVAE_LN2 - (double)log_norm;
-    }
+    for (int d = 0; d < D; ++d) total += (double)tmp[(int64_t)d * cpad + i];
     out[i] = (float)total;
 }
 
@@ -317,9 +331,12 @@ int lvae_launch_lse_shift_bias(float* rbias, int64_t n, PairHeader* hdr, hipStre
 }
 
 int lvae_launch_finalize_pm(const float2* partial, int nsplit, int64_t cpad, int64_t C, int D, int DC,
-                            float log_norm, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(finalize_pm_kernel, dim3((unsigned)lvae_ceil_div(C, 256)), dim3(256), 0, st,
-                       partial, nsplit, cpad, C, D, DC, log_norm, out);
+                            float log_norm, float* tmp, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(finalize_pm_terms_kernel, dim3((unsigned)lvae_ceil_div(C, 256), (unsigned)D), dim3(256), 0,
+                       st, partial, nsplit, cpad, C, DC, log_norm, tmp);
+    LVAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(finalize_pm_sum_kernel, dim3((unsigned)lvae_ceil_div(C, 256)), dim3(256), 0, st, tmp, cpad,
+                       C, D, out);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }
