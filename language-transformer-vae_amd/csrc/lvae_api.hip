@@ -17,7 +17,7 @@ int lvae_launch_finalize(const float2* partial, int nsplit, int64_t cpad, int64_
                          const float* colbias, float log_norm, float* out, float* out_max,
                          float* out_sum, const PairHeader* hdr, float cond_limit, int use_if_above,
                          int use_ref, int* flags_out, const int* flags_in, int group_cols, hipStream_t st);
-int lvae_launch_lse_shift_bias(float* rbias, int64_t n, PairHeader* hdr, hipStream_t st);
+int lvae_launch_lse_shift_bias(float* rbias, int64_t n, int64_t n_valid, PairHeader* hdr, hipStream_t st);
 int lvae_launch_finalize_pm(const float2* partial, int nsplit, int64_t cpad, int64_t C, int D, int DC,
                             float log_norm, float* tmp, float* out, hipStream_t st);
 int lvae_launch_pair_lse_mfma(const PairPlan& p, const float* rfrag, const float* rbias,
@@ -274,7 +274,7 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     if (need_mfma) {
         LVAE_HIP(hipMemsetAsync(redo, 0, (size_t)(p.cpad / 128 + 1) * sizeof(int), st));
         if (fixed_ref) {
-            rc = lvae_launch_lse_shift_bias(rbias, p.nblk * 32, hdr, st);
+            rc = lvae_launch_lse_shift_bias(rbias, p.nblk * 32, N, hdr, st);
             if (rc) return rc;
         }
     }

@@ -78,6 +78,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     }
     // redo pass of the fixed-reference logsumexp: only the flagged workgroups have work
     if (redo_flags && redo_flags[blockIdx.x] == 0) return;
+    if (EPI == 4 && hdr->lse_skip) return;       // the fixed reference cannot hold this call's range of normalisers
     constexpr int NQ = DP / 4;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;

@@ -11,6 +11,9 @@
 // whose total stays below 2^LSE_FLOOR_LOG2 is redone with the running-maximum kernel.
 #define LSE_HEADROOM 100.0f
 #define LSE_FLOOR 8.2718061e-25f     // 2^-80
+// If the typical normaliser sits more than this many bits below the largest one (a few extremely peaked
+// posteriors among broad ones), nearly every column would underflow the fixed reference: skip that pass.
+#define LSE_SKIP_SPREAD 130.0f
 struct KsumParams {
     int poly;
     int n;
@@ -25,7 +28,9 @@ struct PairHeader {
     unsigned int cond_bits;  // float bits of max_j conditioning estimate (non-negative -> uint order)
     unsigned int cmax_key;   // order-preserving key of the largest density normaliser max_j -0.5 log2 prod_d(2 pi var_jd)
     float lse_ref;           // reference the row biases were shifted by: every term <= 2^LSE_HEADROOM
-    unsigned int pad_[61];
+    unsigned int lse_skip;   // 1: the fixed-reference pass is pointless (see lse_shift_bias_kernel), go straight to the redo
+    double norm_sum;         // sum_j of the density normalisers (their mean locates the typical posterior)
+    unsigned int pad_[58];
     KsumParams ksum;         // kernel-matrix epilogue parameters (copied in by the MMD entry point)
     unsigned int pad2_[27];
 };

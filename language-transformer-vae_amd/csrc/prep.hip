@@ -159,9 +159,13 @@ prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ sprea
                     kb = max(kb, (unsigned)__shfl_xor((int)kb, off, 64));
                     nk = max(nk, (unsigned)__shfl_xor((int)nk, off, 64));
                 }
+                float nsum32 = valid ? -0.5f * LVAE_LOG2E * nn : 0.f;
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) nsum32 += __shfl_xor(nsum32, off, 64);
                 if (r == 0) {
                     atomicMax(&hdr->cond_bits, kb);
                     atomicMax(&hdr->cmax_key, nk);
+                    atomicAdd(&hdr->norm_sum, (double)nsum32);
                 }
             }
         }
@@ -195,12 +199,20 @@ __global__ void prep_dparams_kernel(const float* __restrict__ mu, const float* _
 
 // Fixed-reference logsumexp: shift the row biases by ref = (largest normaliser) - LSE_HEADROOM, so that every
 // term 2^(v_ij - ref) is at most 2^LSE_HEADROOM and the pair kernel needs no running maximum.
-__global__ void __launch_bounds__(256) lse_shift_bias_kernel(float* __restrict__ rbias, int64_t n,
+// A sample's total is dominated by posteriors with a typical normaliser; if the mean normaliser is more
+// than LSE_SKIP_SPREAD bits below the largest one, almost every column would come out below the floor and be
+// redone anyway, so the fixed-reference pass is switched off for this call (lse_skip).
+__global__ void __launch_bounds__(256) lse_shift_bias_kernel(float* __restrict__ rbias, int64_t n, int64_t n_valid,
                                                              PairHeader* hdr) {
-    const float ref = lvae_key_float(hdr->cmax_key) - LSE_HEADROOM;
+    const float cmax = lvae_key_float(hdr->cmax_key);
+    const float ref = cmax - LSE_HEADROOM;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) rbias[i] -= ref;          // padding rows stay -inf
-    if (i == 0) hdr->lse_ref = ref;
+    if (i == 0) {
+        hdr->lse_ref = ref;
+        const float mean = (float)(hdr->norm_sum / (double)n_valid);
+        hdr->lse_skip = (cmax - mean > LSE_SKIP_SPREAD) ? 1u : 0u;
+    }
 }
 
 // Merge the per-split (max, sum) partials (base-2 domain) of one kept element into its result.
@@ -223,6 +235,10 @@ __global__ void finalize_lse_kernel(const float2* __restrict__ partial, int nspl
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C) return;
     if (flags_in && flags_in[i / group_cols] == 0) return;
+    if (flags_out && hdr->lse_skip) {        // no fixed-reference pass was run: everything goes to the redo
+        flags_out[i / group_cols] = 1;
+        return;
+    }
     float mx = -INFINITY;
     for (int k = 0; k < nsplit; ++k) mx = fmaxf(mx, partial[k * cpad + i].x);
     double s = 0.0;
@@ -323,9 +339,9 @@ int lvae_launch_finalize(const float2* partial, int nsplit, int64_t cpad, int64_
     return LVAE_OK;
 }
 
-int lvae_launch_lse_shift_bias(float* rbias, int64_t n, PairHeader* hdr, hipStream_t st) {
+int lvae_launch_lse_shift_bias(float* rbias, int64_t n, int64_t n_valid, PairHeader* hdr, hipStream_t st) {
     hipLaunchKernelGGL(lse_shift_bias_kernel, dim3((unsigned)lvae_ceil_div(n, 256)), dim3(256), 0, st, rbias, n,
-                       hdr);
+                       n_valid, hdr);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }

@@ -135,3 +135,26 @@ def test_hip_graph_capture_and_replay():
         ref, refpm = ref - (3.0 - np.log(N_)), refpm - D * (3.0 - np.log(N_))
         np.testing.assert_allclose(lq.cpu().numpy(), ref, rtol=1e-4, atol=1e-3, err_msg=f"trial {trial}")
         np.testing.assert_allclose(lqpm.cpu().numpy(), refpm, rtol=1e-4, atol=1e-3, err_msg=f"trial {trial}")
+
+
+def test_heterogeneous_posteriors_skip_fixed_reference():
+    """A few extremely peaked posteriors among broad ones put the largest density normaliser far above the
+    typical one: the fixed-reference pass would underflow for almost every sample, the device-side test
+    switches it off and the running-maximum kernel does the whole job.  Also the in-between case where
+    only some column groups are redone."""
+    from lvae import estimators as E
+    rng = np.random.default_rng(3)
+    N_, D = 900, 32
+    for n_peaked, lv_peaked in ((5, -14.0), (450, -9.0)):
+        mu = rng.standard_normal((N_, D)).astype(np.float32)
+        logvar = (0.3 * rng.standard_normal((N_, D)) - 0.5).astype(np.float32)
+        logvar[:n_peaked] = lv_peaked
+        mu[:n_peaked] = 1e-3 * rng.standard_normal((n_peaked, D))     # peaked AND near the origin: well conditioned
+        z = (mu + rng.standard_normal((N_, D)) * np.exp(0.5 * logvar)).astype(np.float32)
+        ref, _ = onp.approximate_log_q_z(mu, logvar, z, method="all", prod_marginals=False, reduce_mean=False)
+        lq, _ = E.approximate_log_q_z(dev(mu), dev(logvar), dev(z), method="all", prod_marginals=False,
+                                      reduce_mean=False, path=PATHS["mfma"])
+        np.testing.assert_allclose(lq.cpu().numpy(), ref, rtol=2e-4, atol=2e-3, err_msg=str(n_peaked))
+        lq, _ = E.approximate_log_q_z(dev(mu), dev(logvar), dev(z), method="all", prod_marginals=False,
+                                      reduce_mean=False, path=PATHS["auto"])
+        np.testing.assert_allclose(lq.cpu().numpy(), ref, rtol=2e-4, atol=2e-3, err_msg=str(n_peaked))
