@@ -158,3 +158,27 @@ def test_heterogeneous_posteriors_skip_fixed_reference():
         lq, _ = E.approximate_log_q_z(dev(mu), dev(logvar), dev(z), method="all", prod_marginals=False,
                                       reduce_mean=False, path=PATHS["auto"])
         np.testing.assert_allclose(lq.cpu().numpy(), ref, rtol=2e-4, atol=2e-3, err_msg=str(n_peaked))
+
+
+def test_translation_and_permutation_invariance():
+    """Size-independent properties at a size the oracle would not finish quickly: log q(z) only depends on
+    z - mu (a common translation of both -- here +50 in every dimension -- is removed by the centering shift
+    before the fp32 contraction), and on the SET of posteriors (their order is irrelevant)."""
+    from lvae import estimators as E
+    g = torch.Generator(device="cuda").manual_seed(5)
+    N_, M_, D = 20000, 12000, 32
+    mu = torch.randn(N_, D, device="cuda", generator=g)
+    lv = 0.5 * torch.randn(N_, D, device="cuda", generator=g) - 1.0
+    z = mu[:M_] + torch.randn(M_, D, device="cuda", generator=g) * torch.exp(0.5 * lv[:M_])
+    base, base_pm = E.approximate_log_q_z(mu, lv, z, method="all", prod_marginals=True, reduce_mean=False)
+    moved, moved_pm = E.approximate_log_q_z(mu + 50.0, lv, z + 50.0, method="all", prod_marginals=True,
+                                            reduce_mean=False)
+    perm = torch.randperm(N_, device="cuda", generator=g)
+    shuf, shuf_pm = E.approximate_log_q_z(mu[perm].contiguous(), lv[perm].contiguous(), z, method="all",
+                                          prod_marginals=True, reduce_mean=False)
+    for a, b, tol in ((moved, base, 2e-3), (moved_pm, base_pm, 2e-3), (shuf, base, 2e-4), (shuf_pm, base_pm, 2e-4)):
+        assert float((a - b).abs().max()) <= tol, float((a - b).abs().max())
+        assert abs(float(a.double().mean() - b.double().mean())) <= 1e-4 * abs(float(b.double().mean()))
+    # and the sample under its own posterior bounds the mixture from below: log q(z_i) >= log q(z_i|x_i) - log N
+    own = E.sample_log_likelihood(z, mu[:M_].contiguous(), lv[:M_].contiguous(), reduce_batch_dim=False)
+    assert bool((base >= own - np.log(N_) - 1e-3).all())
