@@ -76,3 +76,24 @@ def test_reparam_iw_vs_c_oracle_large():
     out1 = E.reparam_iw(dev(mu), dev(lv), dev(eps[:, :1]), dev(lpxz[:, :1]))
     w = lpxz[:, 0] + lp[:, 0] - lq[:, 0]
     np.testing.assert_allclose(out1["iw_ll"].cpu().numpy(), w, rtol=1e-4, atol=1e-3)
+
+
+def test_iw_full_size_properties():
+    """BASELINE configs[4] at full size (K = 1,000 samples x 16,384 sentences, D = 32), through properties:
+    a constant added to log p(x|z) shifts the IW estimate by that constant, the estimate lies between the
+    mean and the maximum of the log-weights, and the per-sample densities agree with sample_log_likelihood."""
+    from lvae import estimators as E
+    g = torch.Generator(device="cuda").manual_seed(2)
+    B, K, D = 16384, 1000, 32
+    mu = torch.randn(B, D, device="cuda", generator=g)
+    lv = 0.5 * torch.randn(B, D, device="cuda", generator=g) - 1.0
+    eps = torch.randn(B, K, D, device="cuda", generator=g)
+    lpxz = 5.0 * torch.randn(B, K, device="cuda", generator=g) - 100.0
+    a = E.reparam_iw(mu, lv, eps, lpxz, return_z=True)
+    b = E.reparam_iw(mu, lv, eps, lpxz + 7.5, return_z=False)
+    assert float((b["iw_ll"] - a["iw_ll"] - 7.5).abs().max()) <= 1e-4
+    w = lpxz + a["log_p_z"] - a["log_q_z_x"]
+    assert bool((a["iw_ll"] <= w.max(dim=1).values + 1e-4).all())
+    assert bool((a["iw_ll"] >= w.mean(dim=1) - 1e-3).all())
+    lq = E.sample_log_likelihood(a["latent_z"][:256], mu[:256], lv[:256], reduce_batch_dim=False)
+    assert float((lq - a["log_q_z_x"][:256]).abs().max()) <= 1e-3
