@@ -92,6 +92,13 @@ int lvae_launch_reparam_bwd(const float* logvar, const float* eps, const float* 
 int lvae_launch_kl_bwd(const float* mu, const float* logvar, const float* g_kl, const float* g_hinge,
                        int row_mode, int64_t n, int D, float lambda, float* d_mu, float* d_logvar,
                        hipStream_t st);
+bool lvae_bf16x3_supported(int DP);
+int lvae_launch_prep_bf16x3(bool gauss, bool frag, const float* x, const float* spread, int spread_kind,
+                            int64_t n, int64_t npad, int D, int DP, const PairHeader* hdr, int64_t ngauss,
+                            void* out, hipStream_t st);
+int lvae_launch_pair_bf16x3(const PairPlan& p, const void* rfrag, const float* rbias, const void* cop,
+                            float2* partial, const PairHeader* hdr, int epi, const int* redo_flags,
+                            hipStream_t st);
 int lvae_launch_mmd_stat(const double* sums, int64_t n1, int64_t n2, int unbiased, int zero_alphas,
                          double* out, hipStream_t st);
 
@@ -209,14 +216,20 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
                       float* row_sum, void* ws, int64_t ws_bytes, hipStream_t st) {
     int rc = check_pair_shapes(z, mu, spread, spread_kind, M, N, D);
     if (rc) return rc;
-    LVAE_CHECK_ARG(path == LVAE_PATH_AUTO || path == LVAE_PATH_MFMA || path == LVAE_PATH_DIRECT,
+    LVAE_CHECK_ARG(path == LVAE_PATH_AUTO || path == LVAE_PATH_MFMA || path == LVAE_PATH_DIRECT ||
+                       path == LVAE_PATH_MFMA_BF16X3,
                    "unknown path %d", path);
+    const bool bx = path == LVAE_PATH_MFMA_BF16X3;
+    if (bx) path = LVAE_PATH_MFMA;          // same control flow as the forced fp32 MFMA path, other pair kernel
     const bool with_pm = log_qz_pm != nullptr;
     const PairPlan p = lvae_make_pair_plan(N, M, D, with_pm);
     rc = check_ws(ws, ws_bytes, p.total);
     if (rc) return rc;
     if (path == LVAE_PATH_MFMA && p.DP == 0)
         return lvae_set_error(LVAE_ERR_UNSUPPORTED, "MFMA path needs D <= 128 (got D=%d)", D);
+    if (bx && (!lvae_bf16x3_supported(p.DP) || exclude_diag || N > (1LL << 24)))
+        return lvae_set_error(LVAE_ERR_UNSUPPORTED,
+                              "the bf16x3 path needs D <= 32, no diagonal exclusion and N <= 2^24 (got D=%d)", D);
 
     char* base = (char*)ws;
     PairHeader* hdr = (PairHeader*)(base + p.off_hdr);
@@ -246,14 +259,21 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
         rc = lvae_launch_colsum(mu, N, D, hdr, st);
         if (rc) return rc;
         rc = lvae_launch_prep(0, true, mu, spread, spread_kind, N, p.nblk * 32, D, p.DP, hdr, N,
-                              rfrag, rbias, dparams_now ? dparams : nullptr, p.DC, st);
+                              bx ? nullptr : rfrag, rbias, dparams_now ? dparams : nullptr, p.DC, st);
         if (rc) return rc;
+        if (bx && need_mfma) {   // limb operands into the same regions (the fp32 prep above still owns bias + header)
+            rc = lvae_launch_prep_bf16x3(true, true, mu, spread, spread_kind, N, p.nblk * 32, D, p.DP, hdr, N,
+                                         rfrag, st);
+            if (rc) return rc;
+            rc = lvae_launch_prep_bf16x3(false, false, z, nullptr, 0, M, p.cpad, D, p.DP, hdr, N, cop, st);
+            if (rc) return rc;
+        }
         if (need_direct && !dparams_now) {
             rc = lvae_launch_prep_dparams(mu, spread, spread_kind, N, D, p.DC, dparams,
                                           auto_gate ? hdr : nullptr, LVAE_COND_LIMIT, st);
             if (rc) return rc;
         }
-        if (need_mfma) {
+        if (need_mfma && !bx) {
             rc = lvae_launch_prep(1, false, z, nullptr, 0, M, p.cpad, D, p.DP, hdr, N, cop, nullptr,
                                   nullptr, p.DC, st);
             if (rc) return rc;
@@ -280,8 +300,9 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     }
     hipEvent_t prof_stop = prof_mark(st, nullptr);
     if (need_mfma) {
-        rc = lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, limit, 0, exclude_diag != 0, diag_offset,
-                                   fixed_ref ? 4 : 0, nullptr, 0, st);
+        if (bx) rc = lvae_launch_pair_bf16x3(p, rfrag, rbias, cop, partial, hdr, 4, nullptr, st);
+        else rc = lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, limit, 0, exclude_diag != 0, diag_offset,
+                                        fixed_ref ? 4 : 0, nullptr, 0, st);
         if (rc) return rc;
     }
     if (need_direct) {
@@ -301,8 +322,9 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
                                       nullptr, group_cols, st);
             if (rc) return rc;
             if (fixed_ref) {
-                rc = lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, limit, 0, exclude_diag != 0,
-                                           diag_offset, 0, redo, 0, st);
+                if (bx) rc = lvae_launch_pair_bf16x3(p, rfrag, rbias, cop, partial, hdr, 0, redo, st);
+                else rc = lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, limit, 0, exclude_diag != 0,
+                                                diag_offset, 0, redo, 0, st);
                 if (rc) return rc;
                 rc = lvae_launch_finalize(partial, p.nsplit, p.cpad, M, nullptr, log_norm, log_qz, row_max,
                                           row_sum, hdr, limit, 0, 1, nullptr, redo, group_cols, st);

@@ -128,9 +128,10 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
 
     size_t o = 0;
     p.off_hdr = o;      o = lvae_align256(o + sizeof(PairHeader));
-    p.off_rfrag = o;    o = lvae_align256(o + (size_t)p.nblk * (p.DP ? p.DP : 0) * 64 * sizeof(float));
+    // (x 1.5: the experimental bf16x3 path stores three bf16 limbs per value in the same regions)
+    p.off_rfrag = o;    o = lvae_align256(o + (size_t)p.nblk * (p.DP ? p.DP : 0) * 96 * sizeof(float));
     p.off_rbias = o;    o = lvae_align256(o + ((size_t)p.nblk * 32 + 64) * sizeof(float));
-    p.off_cop = o;      o = lvae_align256(o + (size_t)p.cpad * 2 * p.DP * sizeof(float));
+    p.off_cop = o;      o = lvae_align256(o + (size_t)p.cpad * 3 * p.DP * sizeof(float));
     p.off_colbias = o;  o = lvae_align256(o + (size_t)p.cpad * sizeof(float));
     p.off_partial = o;  o = lvae_align256(o + (size_t)p.nsplit * p.cpad * 2 * sizeof(float));
     p.off_dparams = o;  o = lvae_align256(o + (size_t)R * 3 * p.DC * sizeof(float));

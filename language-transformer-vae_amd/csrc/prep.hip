@@ -118,7 +118,7 @@ prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ sprea
             }
         }
     }
-    if (row < npad) {
+    if (row < npad && out) {
         if (FRAG) {
             f32x4* o = reinterpret_cast<f32x4*>(out + blk * (int64_t)DP * 64 + q * 256);
             o[r] = v0;

@@ -1,0 +1,95 @@
+"""GPU parity of the experimental opt-in split-bf16 pair kernel (LVAE_PATH_MFMA_BF16X3): same goldens, same
+oracle and same tolerances as the fp32 MFMA path it mirrors (D <= 32, no diagonal exclusion)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import oracle_np as onp
+
+pytestmark = pytest.mark.gpu
+BX = 3
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rel(a, b):
+    return abs(float(a) - float(b)) / max(abs(float(b)), 1e-30)
+
+
+@pytest.mark.parametrize("case", ["generic", "ragged", "collapsed", "near_collapsed", "far", "d20", "d16", "n1"])
+def test_bf16x3_golden(case):
+    from lvae import estimators as E
+    g = load_golden("logqz_" + case)
+    mu, logvar, z = dev(g["mu"]), dev(g["logvar"]), dev(g["z"])
+    for tag, method, ds in (("chen10000", "chen", 10000), ("all", "all", None)):
+        lq, lqpm = E.approximate_log_q_z(mu, logvar, z, method=method, dataset_size=ds, prod_marginals=True,
+                                         reduce_mean=False, path=BX)
+        ref, refpm = g[f"log_q_z_{tag}"], g[f"log_q_z_prod_marg_{tag}"]
+        scale = max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(lq.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * scale)
+        np.testing.assert_allclose(lqpm.cpu().numpy(), refpm, rtol=1e-4, atol=1e-4 * scale)
+        assert rel(lq.double().mean(), ref.astype(np.float64).mean()) < 1e-4
+
+
+@pytest.mark.parametrize("N,M,D", [(1000, 777, 32), (4096, 4096, 32), (513, 2049, 16), (200, 100, 8), (33, 1, 5)])
+def test_bf16x3_vs_oracle(N, M, D):
+    from lvae import estimators as E
+    rng = np.random.default_rng(N + M + D)
+    mu = rng.standard_normal((N, D)).astype(np.float32)
+    logvar = (0.5 * rng.standard_normal((N, D)) - 1.0).astype(np.float32)
+    idx = np.arange(M) % N
+    z = (mu[idx] + rng.standard_normal((M, D)) * np.exp(0.5 * logvar[idx])).astype(np.float32)
+    ref, _ = onp.approximate_log_q_z(mu, logvar, z, method="all", prod_marginals=False, reduce_mean=False)
+    lq, _ = E.approximate_log_q_z(dev(mu), dev(logvar), dev(z), method="all", prod_marginals=False,
+                                  reduce_mean=False, path=BX)
+    scale = max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(lq.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * scale)
+    assert rel(lq.double().mean(), ref.mean()) < 1e-4
+
+
+def test_bf16x3_redo_and_skip_branches():
+    """Far samples underflow the fixed reference (redo with the running-maximum epilogue); heterogeneous
+    posteriors switch the fixed-reference pass off altogether."""
+    from lvae import estimators as E
+    rng = np.random.default_rng(3)
+    N_, D = 900, 32
+    mu = rng.standard_normal((N_, D)).astype(np.float32)
+    logvar = (0.3 * rng.standard_normal((N_, D)) - 0.5).astype(np.float32)
+    z = (mu + rng.standard_normal((N_, D)) * np.exp(0.5 * logvar)).astype(np.float32)
+    z[100:180] += 12.0
+    ref, _ = onp.approximate_log_q_z(mu, logvar, z, method="all", prod_marginals=False, reduce_mean=False)
+    lq, _ = E.approximate_log_q_z(dev(mu), dev(logvar), dev(z), method="all", prod_marginals=False,
+                                  reduce_mean=False, path=BX)
+    np.testing.assert_allclose(lq.cpu().numpy(), ref, rtol=2e-4, atol=2e-3)
+    logvar[:5] = -14.0
+    mu[:5] = 1e-3 * rng.standard_normal((5, D))
+    z = (mu + rng.standard_normal((N_, D)) * np.exp(0.5 * logvar)).astype(np.float32)
+    ref, _ = onp.approximate_log_q_z(mu, logvar, z, method="all", prod_marginals=False, reduce_mean=False)
+    lq, _ = E.approximate_log_q_z(dev(mu), dev(logvar), dev(z), method="all", prod_marginals=False,
+                                  reduce_mean=False, path=BX)
+    np.testing.assert_allclose(lq.cpu().numpy(), ref, rtol=2e-4, atol=2e-3)
+
+
+def test_bf16x3_matches_fp32_path_at_full_size():
+    """C2 (N = M = 65,536, D = 32): per-sample agreement with the fp32 MFMA path."""
+    from lvae import estimators as E
+    g = torch.Generator(device="cuda").manual_seed(9)
+    n, D = 65536, 32
+    mu = torch.randn(n, D, device="cuda", generator=g)
+    lv = 0.5 * torch.randn(n, D, device="cuda", generator=g) - 1.0
+    z = mu + torch.randn(n, D, device="cuda", generator=g) * torch.exp(0.5 * lv)
+    a, _ = E.approximate_log_q_z(mu, lv, z, method="all", prod_marginals=False, reduce_mean=False, path=1)
+    b, _ = E.approximate_log_q_z(mu, lv, z, method="all", prod_marginals=False, reduce_mean=False, path=BX)
+    assert float((a - b).abs().max()) < 2e-4
+    assert rel(b.double().mean(), a.double().mean()) < 1e-6
+
+
+def test_bf16x3_rejects_what_it_does_not_cover():
+    from lvae import _native as N
+    from lvae import estimators as E
+    mu = torch.zeros(64, 64, device="cuda")
+    with pytest.raises(N.LvaeError, match="bf16x3"):
+        E.approximate_log_q_z(mu, mu, mu, method="all", prod_marginals=False, reduce_mean=False, path=BX)
