@@ -252,6 +252,25 @@ int lvae_kernel_matrix_f32(const float* x, const float* y, int64_t n1, int64_t n
                            const float* alphas, int n_alpha, float dist_eps, float* out, void* ws,
                            int64_t ws_bytes, void* stream);
 
+/* calc_upper_and_lower_bound_generative_mi (mutual_information.py:251-278): the same two bounds with
+ * Categorical critics, P[j, i] = Categorical(probs = probs[j, :]).log_prob(samples[i]) =
+ * log(clamp(probs[j, s_i] / sum_v probs[j, v], eps, 1 - eps)), eps = 2^-23 (torch's probs_to_logits).
+ * probs [K, V] fp32 (un-normalised rows allowed, as torch allows), samples [K] int64 in [0, V) -- an index
+ * outside that range makes both outputs NaN (nothing is read out of bounds).  out[0] = InfoNCE lower bound
+ * (:135-173), out[1] = MBU upper bound (:176-215); 2 float64 in device memory.  K >= 2. */
+int lvae_categorical_bounds_workspace_bytes(int64_t K, int64_t* out_bytes);
+int lvae_categorical_bounds_f32(const float* probs, const int64_t* samples, int64_t K, int64_t V, double* out,
+                                void* ws, int64_t ws_bytes, void* stream);
+
+/* Two-sample Kolmogorov-Smirnov statistic of two fp32 vectors: the `statistic` of
+ * scipy.stats.ks_2samp(a, b) (two-sided) as called on the importance-weighted log-likelihood vectors at
+ * utils_train.py:496-497 (scipy is a third-party dependency of the reference; 1.15.3 in this image).
+ * out: 3 float64 in device memory: D = max(D+, D-), D+ = max_v(F_a(v) - F_b(v)), D- = max_v(F_b(v) - F_a(v))
+ * clipped to [0, 1].  Inputs must not contain NaN.  n1, n2 >= 1, n1 + n2 <= 2^30. */
+int lvae_ks_2samp_workspace_bytes(int64_t n1, int64_t n2, int64_t* out_bytes);
+int lvae_ks_2samp_f32(const float* a, int64_t n1, const float* b, int64_t n2, double* out, void* ws,
+                      int64_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Measurement aid (no counterpart in the reference): HIP events recorded on the caller's stream
  * around the pair kernels of lvae_log_qz_f32 / lvae_log_qz_partial_f32, so a benchmark can time the

@@ -45,6 +45,12 @@ _SIGNATURES = {
     "lvae_pair_bounds_workspace_bytes": (_int, [_i64, _int, ctypes.POINTER(_i64)]),
     "lvae_pair_bounds_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _int, _int, ctypes.c_void_p,
                                     ctypes.c_void_p, _i64, ctypes.c_void_p]),
+    "lvae_categorical_bounds_workspace_bytes": (_int, [_i64, ctypes.POINTER(_i64)]),
+    "lvae_categorical_bounds_f32": (_int, [_c_f32p, ctypes.c_void_p, _i64, _i64, ctypes.c_void_p, ctypes.c_void_p,
+                                           _i64, ctypes.c_void_p]),
+    "lvae_ks_2samp_workspace_bytes": (_int, [_i64, _i64, ctypes.POINTER(_i64)]),
+    "lvae_ks_2samp_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, ctypes.c_void_p, ctypes.c_void_p, _i64,
+                                 ctypes.c_void_p]),
     "lvae_log_prob_pairs_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _int, _i64, _i64, _int, _c_f32p,
                                        ctypes.c_void_p]),
     "lvae_kl_diag_f32": (_int, [_c_f32p, _c_f32p, _i64, _int, _f32, _c_f32p, _c_f32p, _c_f32p, _c_f32p,

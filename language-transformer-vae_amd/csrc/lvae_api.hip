@@ -92,6 +92,12 @@ int lvae_launch_reparam_bwd(const float* logvar, const float* eps, const float* 
 int lvae_launch_kl_bwd(const float* mu, const float* logvar, const float* g_kl, const float* g_hinge,
                        int row_mode, int64_t n, int D, float lambda, float* d_mu, float* d_logvar,
                        hipStream_t st);
+size_t lvae_cat_bounds_workspace(int64_t K);
+int lvae_launch_cat_bounds(const float* probs, const int64_t* samples, int64_t K, int64_t V, double* out, void* ws,
+                           hipStream_t st);
+size_t lvae_ks_workspace(int64_t n1, int64_t n2);
+int lvae_launch_ks_2samp(const float* a, int64_t n1, const float* b, int64_t n2, double* out, void* ws,
+                         hipStream_t st);
 bool lvae_bf16x3_supported(int DP);
 int lvae_launch_prep_bf16x3(bool gauss, bool frag, const float* x, const float* spread, int spread_kind,
                             int64_t n, int64_t npad, int D, int DP, const PairHeader* hdr, int64_t ngauss,
@@ -689,6 +695,40 @@ extern "C" int lvae_kde_score_f32(const float* X, const float* Y, int64_t n, int
     int rc = check_ws(ws, ws_bytes, ((size_t)nsplit + 1) * m * sizeof(float));
     if (rc) return rc;
     return lvae_launch_kde(X, Y, n, m, d, bw, stabilise, out, (float*)ws, (hipStream_t)stream);
+}
+
+// ---- Categorical MI bounds, KS statistic -------------------------------------------------------------------
+extern "C" int lvae_categorical_bounds_workspace_bytes(int64_t K, int64_t* out_bytes) {
+    LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
+    LVAE_CHECK_ARG(K >= 2, "the MBU bound needs K >= 2 (got %lld)", (long long)K);
+    *out_bytes = (int64_t)lvae_align256(lvae_cat_bounds_workspace(K));
+    return LVAE_OK;
+}
+
+extern "C" int lvae_categorical_bounds_f32(const float* probs, const int64_t* samples, int64_t K, int64_t V,
+                                           double* out, void* ws, int64_t ws_bytes, void* stream) {
+    LVAE_CHECK_ARG(probs && samples && out, "probs, samples and out must be non-NULL");
+    LVAE_CHECK_ARG(K >= 2 && K < (1LL << 31), "the MBU bound needs 2 <= K < 2^31 (got %lld)", (long long)K);
+    LVAE_CHECK_ARG(V >= 1, "need V >= 1");
+    int rc = check_ws(ws, ws_bytes, lvae_align256(lvae_cat_bounds_workspace(K)));
+    if (rc) return rc;
+    return lvae_launch_cat_bounds(probs, samples, K, V, out, ws, (hipStream_t)stream);
+}
+
+extern "C" int lvae_ks_2samp_workspace_bytes(int64_t n1, int64_t n2, int64_t* out_bytes) {
+    LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
+    LVAE_CHECK_ARG(n1 >= 1 && n2 >= 1 && n1 + n2 <= (1LL << 30), "need n1, n2 >= 1 and n1 + n2 <= 2^30");
+    *out_bytes = (int64_t)lvae_ks_workspace(n1, n2);
+    return LVAE_OK;
+}
+
+extern "C" int lvae_ks_2samp_f32(const float* a, int64_t n1, const float* b, int64_t n2, double* out, void* ws,
+                                 int64_t ws_bytes, void* stream) {
+    LVAE_CHECK_ARG(a && b && out, "a, b and out must be non-NULL");
+    LVAE_CHECK_ARG(n1 >= 1 && n2 >= 1 && n1 + n2 <= (1LL << 30), "need n1, n2 >= 1 and n1 + n2 <= 2^30");
+    int rc = check_ws(ws, ws_bytes, lvae_ks_workspace(n1, n2));
+    if (rc) return rc;
+    return lvae_launch_ks_2samp(a, n1, b, n2, out, ws, (hipStream_t)stream);
 }
 
 // ---- MMD -----------------------------------------------------------------------------------------------

@@ -81,12 +81,12 @@ def all_gather_rows(x, group=None, counts=None):
     return out, offsets
 
 
-def hip_local_stats(mu_all, logvar_all, z_local, mu_local, logvar_local, log_norm, prod_marginals):
+def hip_local_stats(mu_all, logvar_all, z_local, mu_local, logvar_local, log_norm, prod_marginals, path=0):
     """Per-rank compute on the HIP path: float64 sums over this rank's rows of
     [log q(z), log prod-marginals (or 0), log p(z), log q(z|x)] and the row count."""
     from . import _native as N
     from . import estimators as E
-    log_q_z, log_q_z_pm = E.log_qz_raw(mu_all, logvar_all, z_local, log_norm, prod_marginals)
+    log_q_z, log_q_z_pm = E.log_qz_raw(mu_all, logvar_all, z_local, log_norm, prod_marginals, path=path)
     z, mu, lv = (N.as_f32(t, n) for t, n in ((z_local, "z"), (mu_local, "mu"), (logvar_local, "logvar")))
     dev = z.device
     with torch.cuda.device(dev):

@@ -144,3 +144,45 @@ def calc_upper_and_lower_bound_representational_mi(batch_latent_samples, batch_m
         gauss_dists = (mu.contiguous(), std.contiguous())
     lower, upper = _bounds(batch_latent_samples, gauss_dists).tolist()
     return lower, upper
+
+
+def _categorical_bounds(probs, samples):
+    probs = N.as_f32(probs, "batch_probs")
+    K, V = probs.shape
+    dev = probs.device
+    samples = samples.to(device=dev, dtype=torch.int64).contiguous()
+    if samples.shape != (K,):
+        raise RuntimeError(f"need one sampled prediction per distribution: {tuple(samples.shape)} vs K={K}")
+    with torch.cuda.device(dev):
+        nbytes = N._i64(0)
+        N.check(N.lib().lvae_categorical_bounds_workspace_bytes(K, nbytes))
+        ws = N.workspace(nbytes.value, dev)
+        out = torch.empty(2, dtype=torch.float64, device=dev)
+        N.check(N.lib().lvae_categorical_bounds_f32(N.ptr(probs), N.ptr(samples), K, V, N.ptr(out), N.ptr(ws),
+                                                    nbytes.value, N.stream_ptr(dev)))
+    return out
+
+
+def calc_upper_and_lower_bound_generative_mi(batch_probs, cat_dists=None, sampled_predictions=None):
+    """mutual_information.py:251-278: InfoNCE / MBU bounds with the decoder's Categorical distributions as
+    critics.  batch_probs [batch, seq_len, vocab]; one class is drawn per row (torch.multinomial on the
+    caller's device, :269) unless ``sampled_predictions`` injects the draw (tests; not in the reference).
+    ``cat_dists``: the reference's optional list of torch Categorical objects (their ``probs`` are used).
+
+    As written the reference only broadcasts for seq_len == 1: it builds K = batch distributions from the
+    first K rows of the flattened [batch * seq_len, vocab] matrix (:271-273) but draws batch * seq_len
+    samples, and subtracts a [K * seq_len] logsumexp from the [K] diagonal (:165-171).  The same condition
+    is enforced here with the error the reference would raise (RuntimeError)."""
+    K = batch_probs.shape[0]
+    flat = batch_probs.reshape(-1, batch_probs.shape[-1])
+    if flat.shape[0] != K:
+        raise RuntimeError(f"The size of tensor a ({K}) must match the size of tensor b ({flat.shape[0]}) at "
+                           "non-singleton dimension 0 (the reference supports seq_len == 1 only)")
+    if not flat.is_cuda:
+        raise N.LvaeError("batch_probs must be a CUDA (HIP) tensor: there is no CPU fallback")
+    if sampled_predictions is None:
+        sampled_predictions = torch.multinomial(flat, num_samples=1).squeeze(1)
+    if cat_dists:
+        flat = torch.stack([d.probs for d in cat_dists]).to(flat.device)
+    lower, upper = _categorical_bounds(flat, sampled_predictions).tolist()
+    return lower, upper

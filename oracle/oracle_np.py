@@ -215,6 +215,53 @@ def calc_upper_and_lower_bound_representational_mi(batch_latent_samples, batch_m
     return mi_bounds_from_pairs(log_prob_pairs(batch_latent_samples, mu, np.exp(0.5 * logvar)))
 
 
+def categorical_log_prob_pairs(probs, samples):
+    """log_prob_pairs (mutual_information.py:108-132) on torch Categorical(probs=row) critics, as
+    calc_upper_and_lower_bound_generative_mi builds them (:271-273): torch normalises the row and takes
+    log(clamp(p, eps, 1 - eps)) with the fp32 machine epsilon (torch.distributions.utils.probs_to_logits),
+    then gathers the sampled class.  P[j, i] = log p_j(samples[i])."""
+    p = np.asarray(probs, dtype=np.float32)
+    pn = p / p.sum(axis=-1, keepdims=True, dtype=np.float32)
+    eps = np.finfo(np.float32).eps
+    logits = np.log(np.clip(pn, eps, 1 - eps).astype(np.float64))
+    return logits[:, np.asarray(samples, dtype=np.int64)]
+
+
+def calc_upper_and_lower_bound_generative_mi(batch_probs, sampled_predictions):
+    """mutual_information.py:251-278 with the multinomial draw (:269) injected.  As written the function
+    only broadcasts for seq_len == 1 (diag [K] against logsumexp [K * seq_len], :165-171), which is the
+    case restated here: batch_probs [K, 1, V] or [K, V]."""
+    p = np.asarray(batch_probs)
+    p = p.reshape(-1, p.shape[-1])
+    return mi_bounds_from_pairs(categorical_log_prob_pairs(p, sampled_predictions))
+
+
+# ----------------------------------------------------------------------------------------------
+# utils_train.py: Pareto-efficient checkpoints and the KS distance between IW-LL vectors
+# ----------------------------------------------------------------------------------------------
+def ks_2samp_statistic(a, b):
+    """The two-sided statistic of scipy.stats.ks_2samp as called at utils_train.py:496-497 (third-party:
+    scipy, 1.15.3 in this image): both samples sorted, empirical CDFs evaluated at every pooled value with
+    side='right', D = max(max(F_a - F_b), clip(-min(F_a - F_b), 0, 1))."""
+    a, b = np.sort(_f64(a).ravel()), np.sort(_f64(b).ravel())
+    pooled = np.concatenate([a, b])
+    d = np.searchsorted(a, pooled, side="right") / a.size - np.searchsorted(b, pooled, side="right") / b.size
+    return float(max(d.max(), min(max(-d.min(), 0.0), 1.0)))
+
+
+def is_pareto_efficient(gains):
+    """utils_train.py:416-431 (gains: higher is better): a point is dropped iff another point is >= it in
+    every coordinate; of several identical points the first one is kept (:429-430).  Brute force O(n^2)."""
+    g = _f64(gains)
+    n = g.shape[0]
+    keep = np.ones(n, dtype=bool)
+    for i in range(n):
+        for j in range(n):
+            if j != i and np.all(g[i] <= g[j]) and (np.any(g[i] < g[j]) or j < i):
+                keep[i] = False
+    return keep
+
+
 # ----------------------------------------------------------------------------------------------
 # utils_latent_analysis_optimisation.py
 # ----------------------------------------------------------------------------------------------

@@ -346,12 +346,40 @@ def case_grad_encode_tail(lo, seed, B, K, D):
     print("wrote grad_encode_tail")
 
 
+def case_mi_generative(mi, name, seed, K, V, peaked):
+    """calc_upper_and_lower_bound_generative_mi (mutual_information.py:251-278) on [K, 1, V] probabilities
+    (seq_len = 1, the only shape the function broadcasts for).  The multinomial draw inside the function
+    is reproduced by re-seeding the global generator before an identical call."""
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(K, V, generator=g) * (4.0 if peaked else 1.0)
+    if peaked:                                 # each row favours "its own" class: a positive MI
+        logits[torch.arange(K), torch.arange(K) % V] += 6.0
+    probs = torch.softmax(logits, dim=1)
+    probs[0, : V // 4] = 0.0                   # exact zeros: exercises the eps clamp of probs_to_logits
+    probs = probs * (0.5 + torch.rand(K, 1, generator=g))      # un-normalised rows are allowed by torch
+    batch_probs = probs.unsqueeze(1).contiguous()
+    torch.manual_seed(seed + 1000)
+    draw = torch.multinomial(batch_probs.reshape(-1, V), num_samples=1).squeeze(1)
+    torch.manual_seed(seed + 1000)
+    lower, upper = mi.calc_upper_and_lower_bound_generative_mi(batch_probs)
+    dists = [torch.distributions.Categorical(probs=probs[i]) for i in range(K)]
+    pairs = mi.log_prob_pairs(dists, draw)
+    out = {"batch_probs": np32(batch_probs), "sampled_predictions": draw.numpy().astype(np.int64),
+           "lower": np.float64(lower), "upper": np.float64(upper), "log_prob_pairs": np32(pairs)}
+    np.savez_compressed(os.path.join(OUT, f"mi_generative_{name}.npz"), **out)
+    print("wrote mi_generative", name, lower, upper)
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference not present; nothing to do")
         return
     torch.set_num_threads(8)
     lo, kde, enc, mi = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-generative-mi":
+        case_mi_generative(mi, "k64_v500", 26, 64, 500, False)
+        case_mi_generative(mi, "k128_v600_peaked", 27, 128, 600, True)
+        return
     case_logqz(lo, "generic", 0, 256, 256, 32, "generic")
     case_logqz(lo, "ragged", 1, 100, 77, 32, "generic")
     case_logqz(lo, "d64", 2, 128, 128, 64, "generic")
@@ -378,6 +406,8 @@ def main():
     case_grad(lo, "near_collapsed", 23, 64, 64, 32, "near_collapsed")
     case_grad_elem(lo, 24, 12, 5, 32)
     case_grad_encode_tail(lo, 25, 32, 3, 32)
+    case_mi_generative(mi, "k64_v500", 26, 64, 500, False)
+    case_mi_generative(mi, "k128_v600_peaked", 27, 128, 600, True)
 
 
 if __name__ == "__main__":
