@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("LVAE_LIB", os.path.join(_HERE, "liblvae.so"))
 
 SPREAD_LOGVAR, SPREAD_VAR = 0, 1
 PATH_AUTO, PATH_MFMA, PATH_DIRECT = 0, 1, 2
+PATH_MFMA_BF16X3 = 3      # experimental, opt-in (include/lvae.h)
 
 _lib = None
 

@@ -68,6 +68,15 @@ def iw(args):
         if isinstance(v, torch.Tensor) and v.numel() > 0 and v.is_floating_point():
             out[k + "_mean"] = float(v.double().mean())
             out[k + "_n"] = int(v.numel())
+    # KS distance between the observed-data and the generated-data IW-LL vectors (the "-D_ks" metric of
+    # utils_train.py:496-499), for every pair the dump holds
+    if torch.cuda.is_available():
+        from . import pareto
+        for obs in ("obs_valid", "obs_train"):
+            for kind in ("log_p_x", "log_p_x_w"):
+                a, b = d.get(f"{kind}_{obs}"), d.get(f"{kind}_gen")
+                if isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and a.numel() and b.numel():
+                    out[f"D_ks_{kind}_{obs}_vs_gen"] = pareto.ks_2samp(a.to(args.device), b.to(args.device))[0]
     print(json.dumps(out))
     return out
 
@@ -88,6 +97,7 @@ def main(argv=None):
     a.set_defaults(fn=analyse)
     i = sub.add_parser("iw", help="summarise an importance-weighted log-likelihood result dict")
     i.add_argument("file")
+    i.add_argument("--device", default="cuda:0")
     i.set_defaults(fn=iw)
     args = ap.parse_args(argv)
     return args.fn(args)

@@ -88,3 +88,24 @@ def test_cli_analyse_matches_oracle(tmp_path, capsys):
     assert abs(out["mi_lower_infonce"] - np.mean(lows)) <= 1e-4 * abs(np.mean(lows))
     assert abs(out["mi_upper_mbu"] - np.mean(ups)) <= 1e-4 * abs(np.mean(ups))
     assert out["mi_bound_batches"] == 5 and "tts_mmd" in out and "mmd_biased" in out
+
+
+@pytest.mark.gpu
+def test_cli_iw_reports_ks_distance(tmp_path, capsys):
+    """The IW result dict of dist_iw_log_likelihood_x_obs_x_gen.py:184-198 -> means + the KS distance between the
+    observed and generated IW-LL vectors (utils_train.py:496-499)."""
+    from scipy import stats
+    from lvae import cli
+    rng = np.random.default_rng(2)
+    d = {k: torch.from_numpy((rng.standard_normal(n) * 15 - 90 + off).astype(np.float32))
+         for k, n, off in (("log_p_x_obs_valid", 3370, 0.0), ("log_p_x_w_obs_valid", 3370, 0.0),
+                           ("log_p_x_gen", 2000, 4.0), ("log_p_x_w_gen", 2000, 1.0))}
+    d["lens_gen"] = torch.arange(2000)
+    p = tmp_path / "iw_result.p"
+    pickle.dump(d, open(p, "wb"))
+    out = cli.main(["iw", str(p)])
+    capsys.readouterr()
+    for kind in ("log_p_x", "log_p_x_w"):
+        want = stats.ks_2samp(d[f"{kind}_obs_valid"].numpy(), d[f"{kind}_gen"].numpy(), method="asymp").statistic
+        assert out[f"D_ks_{kind}_obs_valid_vs_gen"] == want
+    assert abs(out["log_p_x_gen_mean"] - float(d["log_p_x_gen"].double().mean())) < 1e-9
