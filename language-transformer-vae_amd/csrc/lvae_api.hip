@@ -235,7 +235,7 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
         return lvae_set_error(LVAE_ERR_UNSUPPORTED, "MFMA path needs D <= 128 (got D=%d)", D);
     if (bx && (!lvae_bf16x3_supported(p.DP) || exclude_diag || N > (1LL << 24)))
         return lvae_set_error(LVAE_ERR_UNSUPPORTED,
-                              "the bf16x3 path needs D <= 32, no diagonal exclusion and N <= 2^24 (got D=%d)", D);
+                              "the bf16x3 path needs D <= 64, no diagonal exclusion and N <= 2^24 (got D=%d)", D);
 
     char* base = (char*)ws;
     PairHeader* hdr = (PairHeader*)(base + p.off_hdr);

@@ -153,7 +153,7 @@ pair_lse_bf16x3_kernel(const uint4* __restrict__ rfrag, const float* __restrict_
 
     // LDS ring: one stage per block = PIECES KiB + a 256-B piece with the block's 32 row biases
     constexpr int STAGE_V = PIECES * 64 + 16;     // uint4 (16 B) units
-    constexpr int PF = 3, NST = PF + 1;
+    constexpr int PF = DP >= 64 ? 2 : 3, NST = PF + 1;      // D = 64: 24 KiB per stage, three stages (2 x 73 KB per CU)
     __shared__ uint4 ring[NST * STAGE_V];
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -269,8 +269,8 @@ pair_lse_bf16x3_kernel(const uint4* __restrict__ rfrag, const float* __restrict_
                 }
             }
         }
-        // my DMAs of block t_lin+2 have landed (those of t_lin+3 may still fly); after the barrier everybody's
-        // have and everybody is done reading block t_lin's stage
+        // my DMAs of block t_lin+PF-1 have landed (those of t_lin+PF may still fly); after the barrier
+        // everybody's have and everybody is done reading block t_lin's stage
         bx_wait_vmcnt(DMA_PER_WAVE + 1);
         __builtin_amdgcn_s_barrier();
         ++t_lin;
@@ -322,8 +322,7 @@ pair_lse_bf16x3_kernel(const uint4* __restrict__ rfrag, const float* __restrict_
 }
 
 // ---- host launchers ----------------------------------------------------------------------------------
-// (DP = 64 would need a 99 KB ring per workgroup: two workgroups no longer fit a CU)
-bool lvae_bf16x3_supported(int DP) { return DP == 16 || DP == 32; }
+bool lvae_bf16x3_supported(int DP) { return DP == 16 || DP == 32 || DP == 64; }
 
 // bytes of the limb operands: reduced axis (per 32-row block) and kept axis (per element)
 size_t lvae_bf16x3_rfrag_bytes(int64_t nblk, int DP) { return (size_t)nblk * (DP / 8) * 3 * 1024; }
@@ -361,16 +360,20 @@ static int launch_bx(const PairPlan& p, const void* rfrag, const float* rbias, c
 }
 
 // epi 4: fixed-reference pass; epi 0: running-maximum pass (redo_flags may gate it per workgroup).
-// The plan's NCB must be 2 (lvae_make_pair_plan's default for DP 16 / 32).
+// The plan's NCB must be 2 for DP 16 / 32 and 1 for DP 64 (lvae_make_pair_plan's defaults).
 int lvae_launch_pair_bf16x3(const PairPlan& p, const void* rfrag, const float* rbias, const void* cop,
                             float2* partial, const PairHeader* hdr, int epi, const int* redo_flags,
                             hipStream_t st) {
     if (p.cpad % (4 * 32 * p.NCB) != 0)
         return lvae_set_error(LVAE_ERR_INVALID, "pair plan: cpad %lld not a multiple of the tile", (long long)p.cpad);
+    if (p.DP <= 32 && p.NCB != 2) return lvae_set_error(LVAE_ERR_INVALID, "pair plan: NCB must be 2 at D <= 32");
     switch (p.DP) {
         case 16: return launch_bx<16, 2, 2>(p, rfrag, rbias, cop, partial, hdr, epi, redo_flags, st);
         case 32: return launch_bx<32, 2, 2>(p, rfrag, rbias, cop, partial, hdr, epi, redo_flags, st);
+        case 64:
+            if (p.NCB != 1) return lvae_set_error(LVAE_ERR_INVALID, "pair plan: NCB must be 1 at D = 64");
+            return launch_bx<64, 1, 2>(p, rfrag, rbias, cop, partial, hdr, epi, redo_flags, st);
         default:
-            return lvae_set_error(LVAE_ERR_UNSUPPORTED, "the bf16x3 path needs D <= 32 (got D=%d)", p.D);
+            return lvae_set_error(LVAE_ERR_UNSUPPORTED, "the bf16x3 path needs D <= 64 (got D=%d)", p.D);
     }
 }

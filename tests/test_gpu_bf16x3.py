@@ -1,5 +1,5 @@
 """GPU parity of the experimental opt-in split-bf16 pair kernel (LVAE_PATH_MFMA_BF16X3): same goldens, same
-oracle and same tolerances as the fp32 MFMA path it mirrors (D <= 32, no diagonal exclusion)."""
+oracle and same tolerances as the fp32 MFMA path it mirrors (D <= 64, no diagonal exclusion)."""
 import numpy as np
 import pytest
 import torch
@@ -19,7 +19,7 @@ def rel(a, b):
     return abs(float(a) - float(b)) / max(abs(float(b)), 1e-30)
 
 
-@pytest.mark.parametrize("case", ["generic", "ragged", "collapsed", "near_collapsed", "far", "d20", "d16", "n1"])
+@pytest.mark.parametrize("case", ["generic", "ragged", "d64", "collapsed", "near_collapsed", "far", "d20", "d16", "n1"])
 def test_bf16x3_golden(case):
     from lvae import estimators as E
     g = load_golden("logqz_" + case)
@@ -34,7 +34,8 @@ def test_bf16x3_golden(case):
         assert rel(lq.double().mean(), ref.astype(np.float64).mean()) < 1e-4
 
 
-@pytest.mark.parametrize("N,M,D", [(1000, 777, 32), (4096, 4096, 32), (513, 2049, 16), (200, 100, 8), (33, 1, 5)])
+@pytest.mark.parametrize("N,M,D", [(1000, 777, 32), (4096, 4096, 32), (513, 2049, 16), (200, 100, 8), (33, 1, 5),
+                                    (513, 2049, 64), (3000, 4100, 48)])
 def test_bf16x3_vs_oracle(N, M, D):
     from lvae import estimators as E
     rng = np.random.default_rng(N + M + D)
@@ -73,23 +74,23 @@ def test_bf16x3_redo_and_skip_branches():
     np.testing.assert_allclose(lq.cpu().numpy(), ref, rtol=2e-4, atol=2e-3)
 
 
-def test_bf16x3_matches_fp32_path_at_full_size():
-    """C2 (N = M = 65,536, D = 32): per-sample agreement with the fp32 MFMA path."""
+@pytest.mark.parametrize("n,D", [(65536, 32), (32768, 64)])
+def test_bf16x3_matches_fp32_path_at_full_size(n, D):
+    """C2 (N = M = 65,536, D = 32) and a D = 64 case: per-sample agreement with the fp32 MFMA path."""
     from lvae import estimators as E
     g = torch.Generator(device="cuda").manual_seed(9)
-    n, D = 65536, 32
     mu = torch.randn(n, D, device="cuda", generator=g)
     lv = 0.5 * torch.randn(n, D, device="cuda", generator=g) - 1.0
     z = mu + torch.randn(n, D, device="cuda", generator=g) * torch.exp(0.5 * lv)
     a, _ = E.approximate_log_q_z(mu, lv, z, method="all", prod_marginals=False, reduce_mean=False, path=1)
     b, _ = E.approximate_log_q_z(mu, lv, z, method="all", prod_marginals=False, reduce_mean=False, path=BX)
-    assert float((a - b).abs().max()) < 2e-4
+    assert float((a - b).abs().max()) < 2e-4 * (D / 32)
     assert rel(b.double().mean(), a.double().mean()) < 1e-6
 
 
 def test_bf16x3_rejects_what_it_does_not_cover():
     from lvae import _native as N
     from lvae import estimators as E
-    mu = torch.zeros(64, 64, device="cuda")
+    mu = torch.zeros(64, 100, device="cuda")
     with pytest.raises(N.LvaeError, match="bf16x3"):
         E.approximate_log_q_z(mu, mu, mu, method="all", prod_marginals=False, reduce_mean=False, path=BX)

@@ -19,6 +19,6 @@ def run(n, D, path, reps=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 
-for n, D in ((65536, 32), (65536, 16), (16384, 32), (131072, 32)):
+for n, D in ((65536, 32), (65536, 16), (16384, 32), (131072, 32), (65536, 64), (32768, 64)):
     t1, t3 = run(n, D, 1), run(n, D, 3)
     print(f"n={n} D={D}: fp32 MFMA {t1:.3f} ms ({n*n/t1*1e-9:.2f} Gpair/ms-> {n*n/t1/1e9:.1f}e12/s)  bf16x3 {t3:.3f} ms ({n*n/t3/1e9:.2f}e12 pairs/s)  x{t1/t3:.2f}", flush=True)
