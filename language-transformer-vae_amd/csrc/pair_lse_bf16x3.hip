@@ -269,9 +269,10 @@ pair_lse_bf16x3_kernel(const uint4* __restrict__ rfrag, const float* __restrict_
                 }
             }
         }
-        // my DMAs of block t_lin+PF-1 have landed (those of t_lin+PF may still fly); after the barrier
-        // everybody's have and everybody is done reading block t_lin's stage
-        bx_wait_vmcnt(DMA_PER_WAVE + 1);
+        // the NEXT block's last step reads step 0 and the biases of block t_lin+2, so my DMAs up to block
+        // t_lin+2 must have landed (block t_lin+3, if the ring is that deep, may still fly); after the
+        // barrier everybody's have and everybody is done reading block t_lin's stage
+        bx_wait_vmcnt((PF - 2) * (DMA_PER_WAVE + 1));
         __builtin_amdgcn_s_barrier();
         ++t_lin;
     };
