@@ -41,8 +41,8 @@ typedef enum {
 #define LVAE_PATH_MFMA 1       /* fp32 MFMA quadratic expansion                */
 #define LVAE_PATH_DIRECT 2     /* VALU direct form (z-mu)^2 p, no cancellation */
 #define LVAE_PATH_MFMA_BF16X3 3 /* EXPERIMENTAL, opt-in: the same expansion as three bf16 limbs per value (six
-                                * limb products, fp32 accumulate, fp32-equivalent accuracy); D <= 64, no
-                                * diagonal exclusion; never chosen by LVAE_PATH_AUTO */
+                                * limb products, fp32 accumulate, fp32-equivalent accuracy); D <= 64; never
+                                * chosen by LVAE_PATH_AUTO */
 
 const char* lvae_last_error(void);
 int lvae_version(void);
@@ -270,6 +270,17 @@ int lvae_categorical_bounds_f32(const float* probs, const int64_t* samples, int6
 int lvae_ks_2samp_workspace_bytes(int64_t n1, int64_t n2, int64_t* out_bytes);
 int lvae_ks_2samp_f32(const float* a, int64_t n1, const float* b, int64_t n2, double* out, void* ws,
                       int64_t ws_bytes, void* stream);
+
+/* EXPERIMENTAL, opt-in, process-wide (no counterpart in the reference): the contraction behind the entry
+ * points that have no `path` argument (lvae_mmd_rbf_f32, lvae_kernel_sum_f32, lvae_mmd_perm_f32).
+ * LVAE_MATH_FP32 (default): fp32 MFMA.  LVAE_MATH_BF16X3: three bf16 limbs per fp32 value, six limb products on
+ * the bf16 matrix pipe, fp32 accumulate (fp32-equivalent results) wherever the kernel supports it (D <= 64;
+ * larger D silently stays on fp32).  Read when a call is issued; not meant to be flipped while calls of other
+ * threads are being issued. */
+#define LVAE_MATH_FP32 0
+#define LVAE_MATH_BF16X3 1
+int lvae_set_pair_math(int mode);
+int lvae_get_pair_math(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Measurement aid (no counterpart in the reference): HIP events recorded on the caller's stream

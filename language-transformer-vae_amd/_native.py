@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("LVAE_LIB", os.path.join(_HERE, "liblvae.so"))
 SPREAD_LOGVAR, SPREAD_VAR = 0, 1
 PATH_AUTO, PATH_MFMA, PATH_DIRECT = 0, 1, 2
 PATH_MFMA_BF16X3 = 3      # experimental, opt-in (include/lvae.h)
+MATH_FP32, MATH_BF16X3 = 0, 1
 
 _lib = None
 
@@ -52,6 +53,8 @@ _SIGNATURES = {
     "lvae_ks_2samp_workspace_bytes": (_int, [_i64, _i64, ctypes.POINTER(_i64)]),
     "lvae_ks_2samp_f32": (_int, [_c_f32p, _i64, _c_f32p, _i64, ctypes.c_void_p, ctypes.c_void_p, _i64,
                                  ctypes.c_void_p]),
+    "lvae_set_pair_math": (_int, [_int]),
+    "lvae_get_pair_math": (_int, []),
     "lvae_log_prob_pairs_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _int, _i64, _i64, _int, _c_f32p,
                                        ctypes.c_void_p]),
     "lvae_kl_diag_f32": (_int, [_c_f32p, _c_f32p, _i64, _int, _f32, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
@@ -179,3 +182,29 @@ def colmean_f32(x):
 def host_floats(values):
     arr = (ctypes.c_float * len(values))(*[float(v) for v in values])
     return arr, len(values)
+
+
+def set_pair_math(mode):
+    """Process-wide contraction of the kernel-sum / MMD entry points: MATH_FP32 (default) or MATH_BF16X3
+    (experimental, include/lvae.h)."""
+    check(lib().lvae_set_pair_math(int(mode)))
+
+
+def get_pair_math():
+    return lib().lvae_get_pair_math()
+
+
+class pair_math:
+    """``with pair_math(MATH_BF16X3): ...`` -- set the mode for a block and restore the previous one."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.old = get_pair_math()
+        set_pair_math(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_pair_math(self.old)
+        return False

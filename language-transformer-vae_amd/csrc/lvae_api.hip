@@ -45,6 +45,9 @@ int lvae_launch_latent_sums(const float* z, const float* mu, const float* logvar
 int lvae_launch_pair_mfma(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                           float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
                           bool excl, int64_t excl_offset, int epi, const int* redo_flags, int sym, hipStream_t st);
+int lvae_launch_pair_bf16x3(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
+                          float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
+                          bool excl, int64_t excl_offset, int epi, const int* redo_flags, int sym, hipStream_t st);
 int lvae_launch_finalize_ksum(const double* partial, int nsplit, int64_t cpad, int64_t C, double* out,
                               hipStream_t st);
 int lvae_launch_kl(const float* mu, const float* logvar, int64_t n, int D, float lambda, float* kl_elem,
@@ -99,12 +102,12 @@ size_t lvae_ks_workspace(int64_t n1, int64_t n2);
 int lvae_launch_ks_2samp(const float* a, int64_t n1, const float* b, int64_t n2, double* out, void* ws,
                          hipStream_t st);
 bool lvae_bf16x3_supported(int DP);
-int lvae_launch_prep_bf16x3(bool gauss, bool frag, const float* x, const float* spread, int spread_kind,
+int lvae_launch_pair_bf16x3_perm(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
+                                 float2* partial, const PairHeader* hdr, int64_t excl_offset, int epi,
+                                 const PermArgs& pa, int sym, hipStream_t st);
+int lvae_launch_prep_bf16x3(int src, bool frag, const float* x, const float* spread, int spread_kind,
                             int64_t n, int64_t npad, int D, int DP, const PairHeader* hdr, int64_t ngauss,
                             void* out, hipStream_t st);
-int lvae_launch_pair_bf16x3(const PairPlan& p, const void* rfrag, const float* rbias, const void* cop,
-                            float2* partial, const PairHeader* hdr, int epi, const int* redo_flags,
-                            hipStream_t st);
 int lvae_launch_mmd_stat(const double* sums, int64_t n1, int64_t n2, int unbiased, int zero_alphas,
                          double* out, hipStream_t st);
 
@@ -126,6 +129,7 @@ extern "C" int lvae_version(void) { return 100; }
 // HIP events recorded on the caller's stream right around the pair kernels, so a benchmark can price
 // the dominant kernel alone while timing whole calls.  Off by default; not thread-safe by design
 // (a measurement facility, one measuring thread).
+#include <atomic>
 #include <mutex>
 #include <vector>
 static std::mutex g_prof_mu;
@@ -233,9 +237,9 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     if (rc) return rc;
     if (path == LVAE_PATH_MFMA && p.DP == 0)
         return lvae_set_error(LVAE_ERR_UNSUPPORTED, "MFMA path needs D <= 128 (got D=%d)", D);
-    if (bx && (!lvae_bf16x3_supported(p.DP) || exclude_diag || N > (1LL << 24)))
-        return lvae_set_error(LVAE_ERR_UNSUPPORTED,
-                              "the bf16x3 path needs D <= 64, no diagonal exclusion and N <= 2^24 (got D=%d)", D);
+    if (bx && !lvae_bf16x3_supported(p.DP))
+        return lvae_set_error(LVAE_ERR_UNSUPPORTED, "the bf16x3 path needs D <= 64 (got D=%d)", D);
+    const auto launch_pair = bx ? lvae_launch_pair_bf16x3 : lvae_launch_pair_mfma;
 
     char* base = (char*)ws;
     PairHeader* hdr = (PairHeader*)(base + p.off_hdr);
@@ -268,10 +272,10 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
                               bx ? nullptr : rfrag, rbias, dparams_now ? dparams : nullptr, p.DC, st);
         if (rc) return rc;
         if (bx && need_mfma) {   // limb operands into the same regions (the fp32 prep above still owns bias + header)
-            rc = lvae_launch_prep_bf16x3(true, true, mu, spread, spread_kind, N, p.nblk * 32, D, p.DP, hdr, N,
+            rc = lvae_launch_prep_bf16x3(0, true, mu, spread, spread_kind, N, p.nblk * 32, D, p.DP, hdr, N,
                                          rfrag, st);
             if (rc) return rc;
-            rc = lvae_launch_prep_bf16x3(false, false, z, nullptr, 0, M, p.cpad, D, p.DP, hdr, N, cop, st);
+            rc = lvae_launch_prep_bf16x3(1, false, z, nullptr, 0, M, p.cpad, D, p.DP, hdr, N, cop, st);
             if (rc) return rc;
         }
         if (need_direct && !dparams_now) {
@@ -306,9 +310,8 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     }
     hipEvent_t prof_stop = prof_mark(st, nullptr);
     if (need_mfma) {
-        if (bx) rc = lvae_launch_pair_bf16x3(p, rfrag, rbias, cop, partial, hdr, 4, nullptr, st);
-        else rc = lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, limit, 0, exclude_diag != 0, diag_offset,
-                                        fixed_ref ? 4 : 0, nullptr, 0, st);
+        rc = launch_pair(p, rfrag, rbias, cop, partial, hdr, limit, 0, exclude_diag != 0, diag_offset,
+                         fixed_ref ? 4 : 0, nullptr, 0, st);
         if (rc) return rc;
     }
     if (need_direct) {
@@ -328,9 +331,8 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
                                       nullptr, group_cols, st);
             if (rc) return rc;
             if (fixed_ref) {
-                if (bx) rc = lvae_launch_pair_bf16x3(p, rfrag, rbias, cop, partial, hdr, 0, redo, st);
-                else rc = lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, limit, 0, exclude_diag != 0,
-                                                diag_offset, 0, redo, 0, st);
+                rc = launch_pair(p, rfrag, rbias, cop, partial, hdr, limit, 0, exclude_diag != 0, diag_offset, 0,
+                                 redo, 0, st);
                 if (rc) return rc;
                 rc = lvae_launch_finalize(partial, p.nsplit, p.cpad, M, nullptr, log_norm, log_qz, row_max,
                                           row_sum, hdr, limit, 0, 1, nullptr, redo, group_cols, st);
@@ -791,6 +793,35 @@ static int ksum_epi(const KsumParams& kp) {
     return kp.n <= 1 ? 1 : (kp.n <= 16 ? 2 : 3);
 }
 
+// Process-wide choice of the contraction behind the kernel-sum / MMD entry points (which have no `path`
+// argument): 0 = fp32 MFMA (default), 1 = split-bf16 where the kernel supports it (D <= 64).
+static std::atomic<int> g_pair_math{LVAE_MATH_FP32};
+
+extern "C" int lvae_set_pair_math(int mode) {
+    LVAE_CHECK_ARG(mode == LVAE_MATH_FP32 || mode == LVAE_MATH_BF16X3, "unknown pair math mode %d", mode);
+    g_pair_math.store(mode);
+    return LVAE_OK;
+}
+
+extern "C" int lvae_get_pair_math(void) { return g_pair_math.load(); }
+
+static bool ksum_use_bx(const PairPlan& p) {
+    return g_pair_math.load() == LVAE_MATH_BF16X3 && lvae_bf16x3_supported(p.DP);
+}
+
+// Operands of a kernel-sum pass: reduced axis = points b (POINT rows, fragment-major, + |b|^2 biases), kept
+// axis = points a (SAMPLE rows).  bx: the limb operands replace the fp32 ones in the same regions.
+static int prep_ksum_operands(const PairPlan& p, bool bx, const float* a, int64_t na, const float* b, int64_t nb,
+                              int D, PairHeader* hdr, float* rfrag, float* rbias, float* cop, hipStream_t st) {
+    int rc = lvae_launch_prep(2, true, b, nullptr, 0, nb, p.nblk * 32, D, p.DP, hdr, 1, bx ? nullptr : rfrag, rbias,
+                              nullptr, p.DC, st);
+    if (rc) return rc;
+    if (!bx) return lvae_launch_prep(1, false, a, nullptr, 0, na, p.cpad, D, p.DP, hdr, 1, cop, nullptr, nullptr, p.DC, st);
+    rc = lvae_launch_prep_bf16x3(2, true, b, nullptr, 0, nb, p.nblk * 32, D, p.DP, hdr, 1, rfrag, st);
+    if (rc) return rc;
+    return lvae_launch_prep_bf16x3(1, false, a, nullptr, 0, na, p.cpad, D, p.DP, hdr, 1, cop, st);
+}
+
 static int ksum_pass(const float* a, int64_t na, const float* b, int64_t nb, int D, bool excl, int epi,
                      void* ws, double* out, hipStream_t st) {
     const PairPlan p = lvae_make_pair_plan(nb, na, D, false, 0, a == b);
@@ -800,12 +831,11 @@ static int ksum_pass(const float* a, int64_t na, const float* b, int64_t nb, int
     float* rbias = (float*)(base + p.off_rbias);
     float* cop = (float*)(base + p.off_cop);
     float2* partial = (float2*)(base + p.off_partial);
-    int rc = lvae_launch_prep(2, true, b, nullptr, 0, nb, p.nblk * 32, D, p.DP, hdr, 1, rfrag, rbias, nullptr,
-                              p.DC, st);
+    const bool bx = ksum_use_bx(p);
+    int rc = prep_ksum_operands(p, bx, a, na, b, nb, D, hdr, rfrag, rbias, cop, st);
     if (rc) return rc;
-    rc = lvae_launch_prep(1, false, a, nullptr, 0, na, p.cpad, D, p.DP, hdr, 1, cop, nullptr, nullptr, p.DC, st);
-    if (rc) return rc;
-    rc = lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, -1.f, 0, excl, 0, epi, nullptr, a == b ? 1 : 0, st);
+    rc = (bx ? lvae_launch_pair_bf16x3 : lvae_launch_pair_mfma)(p, rfrag, rbias, cop, partial, hdr, -1.f, 0, excl, 0,
+                                                                epi, nullptr, a == b ? 1 : 0, st);
     if (rc) return rc;
     return lvae_launch_finalize_ksum((const double*)partial, p.nsplit, p.cpad, na, out, st);
 }
@@ -883,15 +913,13 @@ extern "C" int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, i
     if (kp.n == 0 && kp.c[0] == 0.f) {      // only alpha = 0 bandwidths: no pair kernel needed
         LVAE_HIP(hipMemsetAsync(partial, 0, (size_t)p.nsplit * p.cpad * sizeof(double), st));
     } else {
-        rc = lvae_launch_prep(2, true, b, nullptr, 0, nb, p.nblk * 32, D, p.DP, hdr, 1,
-                              (float*)(base + p.off_rfrag), (float*)(base + p.off_rbias), nullptr, p.DC, st);
+        const bool bx = ksum_use_bx(p);
+        rc = prep_ksum_operands(p, bx, a, na, b, nb, D, hdr, (float*)(base + p.off_rfrag),
+                                (float*)(base + p.off_rbias), (float*)(base + p.off_cop), st);
         if (rc) return rc;
-        rc = lvae_launch_prep(1, false, a, nullptr, 0, na, p.cpad, D, p.DP, hdr, 1, (float*)(base + p.off_cop),
-                              nullptr, nullptr, p.DC, st);
-        if (rc) return rc;
-        rc = lvae_launch_pair_mfma(p, (float*)(base + p.off_rfrag), (float*)(base + p.off_rbias),
-                                   (float*)(base + p.off_cop), partial, hdr, -1.f, 0, exclude_diag != 0,
-                                   diag_offset, ksum_epi(kp), nullptr, sym, st);
+        rc = (bx ? lvae_launch_pair_bf16x3 : lvae_launch_pair_mfma)(
+            p, (float*)(base + p.off_rfrag), (float*)(base + p.off_rbias), (float*)(base + p.off_cop), partial, hdr,
+            -1.f, 0, exclude_diag != 0, diag_offset, ksum_epi(kp), nullptr, sym, st);
         if (rc) return rc;
     }
     return lvae_launch_ksum_columns((const double*)partial, p.nsplit, p.cpad, na, nb, exclude_diag != 0,
@@ -950,11 +978,9 @@ extern "C" int lvae_mmd_perm_f32(const float* cols, int64_t nc, int64_t col_offs
     }
     rc = lvae_launch_prep_labels(labels, P, n, p.nblk, labfrag, st);
     if (rc) return rc;
-    rc = lvae_launch_prep(2, true, pooled, nullptr, 0, n, p.nblk * 32, D, p.DP, hdr, 1,
-                          (float*)(base + p.off_rfrag), (float*)(base + p.off_rbias), nullptr, p.DC, st);
-    if (rc) return rc;
-    rc = lvae_launch_prep(1, false, cols, nullptr, 0, nc, p.cpad, D, p.DP, hdr, 1, (float*)(base + p.off_cop),
-                          nullptr, nullptr, p.DC, st);
+    const bool bx = ksum_use_bx(p);
+    rc = prep_ksum_operands(p, bx, cols, nc, pooled, n, D, hdr, (float*)(base + p.off_rfrag),
+                            (float*)(base + p.off_rbias), (float*)(base + p.off_cop), st);
     if (rc) return rc;
     PermArgs pa{};
     pa.labfrag = labfrag;
@@ -965,9 +991,9 @@ extern "C" int lvae_mmd_perm_f32(const float* cols, int64_t nc, int64_t col_offs
     pa.col_offset = col_offset;
     pa.C = nc;
     pa.P = P;
-    rc = lvae_launch_pair_mfma_perm(p, (float*)(base + p.off_rfrag), (float*)(base + p.off_rbias),
-                                    (float*)(base + p.off_cop), partial, hdr, col_offset, ksum_epi(kp), pa, sym,
-                                    st);
+    rc = (bx ? lvae_launch_pair_bf16x3_perm : lvae_launch_pair_mfma_perm)(
+        p, (float*)(base + p.off_rfrag), (float*)(base + p.off_rbias), (float*)(base + p.off_cop), partial, hdr,
+        col_offset, ksum_epi(kp), pa, sym, st);
     if (rc) return rc;
     return lvae_launch_perm_lr((const double*)partial, diag_partial, p.nsplit, p.cpad, nc, labels, n, col_offset,
                                P, sym, qperm, out, st);

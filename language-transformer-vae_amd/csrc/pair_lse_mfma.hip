@@ -1,570 +1,5 @@
-// Fused pair log-density + streaming logsumexp on the fp32 matrix cores (gfx950).
-//
-//   out[c] = log2 sum_r 2^( sum_k Rop[r][k] * Cop[c][k] + rbias[r] )          (base-2 domain)
-//
-// r runs over the REDUCED axis (posteriors for log q(z)), c over the KEPT axis (samples).  Operands
-// come from prep.hip.  Each wave owns 32*NCB kept elements for its whole life: their operand rows sit
-// in VGPRs as the B operand of v_mfma_f32_32x32x2_f32 (lane = column + 32*half).  The wave then streams
-// 32-row blocks of the reduced axis through an LDS ring shared by the workgroup's four waves and filled
-// by LDS-DMA (one 1 KiB piece per 4 MFMA steps, fragment-major layout), the accumulators start from the
-// row bias, DP chained MFMAs per 32x32 tile produce the base-2 log-densities, and the epilogue folds the
-// 16 values a lane holds (16 reduced rows of its own column) into that lane's sum.  The reduction axis
-// lives on the MFMA ROW index, i.e. in registers, so the logsumexp needs no cross-lane traffic until the
-// very end, where the two half-waves (rows +0..3 / +4..7 of every 8) are merged with one wave shuffle.
-//
-// Two logsumexp epilogues (template parameter EPI):
-//   EPI 4  fixed reference: lse_shift_bias_kernel has folded -(largest density normaliser - 100) into the
-//          row biases, every term is <= 2^100, and a tile costs 16 v_exp_f32 + 8 v_pk_add_f32.  Columns
-//          whose total underflows are flagged by finalize_lse_kernel and redone with
-//   EPI 0  running maximum, updated lazily: the tile sum of exponentials relative to the running max
-//          proves (all terms are positive) that no term exceeded it by LSE_THR bits; otherwise the wave
-//          redoes the tile against the true maximum.  Sums stay below 2^LSE_THR * R.
-//
-// Bound: fp32 MFMA (157.3 TFLOP/s); algorithmic cost 4*D flop per pair.  HBM traffic is negligible
-// (operands are L2/Infinity-Cache resident and re-read by every wave).
-#include "pair_plan.h"
-
-#define LSE_THR 8.0f
-#define LSE_BIG 256.0f      // 2^LSE_THR
-
-// s_waitcnt vmcnt(n) for a small n known after unrolling
-__device__ __forceinline__ void wait_vmcnt(int n) {
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-#define LSE_MINIT (-1.0e30f)
-
-// EPI 0 / 4: streaming logsumexp (log q(z), q_z_estimate, MI bounds), see above.
-// EPI 1-3: kernel-matrix column sums.  The contraction is the squared distance d2 = |x - y|^2 (POINT x
-//        SAMPLE operands) and every pair contributes f(d2) = sum_k exp(-alpha_k * (eps + |d2|)),
-//        accumulated per column in float64 (one tile's 16 terms are first summed in float32).
-//        EPI 1: one bandwidth; EPI 2: alpha_k = base * (integer <= 16), f is a polynomial in
-//        t = exp(-base*v) evaluated by Horner's rule on the packed fp32 pipe (one v_exp_f32 per pair for
-//        any number of bandwidths); EPI 3: one exponential per bandwidth.
-//        sym: a sample against itself -- only the tiles on and above the diagonal are visited.
-// PERM (with EPI 1/2, NCB == 1): label-permutation sums for the MMD permutation test.  Every 32x32
-//        tile of kernel values K[r][c] is, straight from the accumulator layout, the A operand
-//        (i = column c, k = row r) of v_mfma_f32_32x32x16_bf16 against 0/1 label fragments
-//        L[r][p] (128 labelings, four 32-wide tiles), split into two bf16 limbs (hi + lo, ~17 bits):
-//        Y[c][p] += sum_r K[r][c] L[r][p].  Every PERM_FLUSH blocks the lane folds
-//        sum_c L[c][p] Y[c][p] into a float64 and clears Y; at the end q_p = L_p^T K L_p partials go
-//        to `qperm` with float64 atomics.
-#define PERM_FLUSH 16
-
-template <int DP, int NCB, int WPS, bool EXCL, int EPI, bool PERM = false>
-__global__ void __launch_bounds__(256, WPS)
-pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ rbias,
-                     const float* __restrict__ cop, float2* __restrict__ partial,
-                     const PairHeader* __restrict__ hdr, float cond_limit, int use_if_above,
-                     int64_t nblk, int64_t blk_per_split, int64_t cpad, int64_t excl_offset,
-                     PermArgs pa, const int* __restrict__ redo_flags, int sym) {
-    static_assert(!PERM || (NCB == 1 && (EPI == 1 || EPI == 2)), "PERM needs NCB == 1 and a polynomial epilogue");
-    // Path gate: the conditioning estimate written by prep decides between this kernel and the direct
-    // one without a host round trip (both are launched; the unselected one exits here).
-    if (cond_limit >= 0.f) {
-        const float cond = __uint_as_float(hdr->cond_bits);
-        if ((cond > cond_limit) != (use_if_above != 0)) return;
-    }
-    // redo pass of the fixed-reference logsumexp: only the flagged workgroups have work
-    if (redo_flags && redo_flags[blockIdx.x] == 0) return;
-    if (EPI == 4 && hdr->lse_skip) return;       // the fixed reference cannot hold this call's range of normalisers
-    constexpr int NQ = DP / 4;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int r = lane & 31;
-    const int h = lane >> 5;
-    const int64_t col0 = ((int64_t)blockIdx.x * 4 + wave) * (32 * NCB);
-
-    // kept-axis operand: resident for the whole kernel
-    float bz[NCB][DP];
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(cop + (col0 + cb * 32 + r) * (2 * DP) + h * DP);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const f32x4 v = src[q];
-            bz[cb][4 * q + 0] = v[0];
-            bz[cb][4 * q + 1] = v[1];
-            bz[cb][4 * q + 2] = v[2];
-            bz[cb][4 * q + 3] = v[3];
-        }
-    }
-
-    float m[NCB], s[NCB];
-    double ks[NCB];       // EPI 1: float64 column sums
-    double ksd = 0.0;     // PERM + sym: column sums of the diagonal tile
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-        m[cb] = LSE_MINIT;
-        s[cb] = 0.f;
-        ks[cb] = 0.0;
-    }
-
-    int64_t b0 = (int64_t)blockIdx.y * blk_per_split;
-    int64_t b1 = b0 + blk_per_split;
-    if (b1 > nblk) b1 = nblk;
-    // sym (kernel sums of a sample against itself, totals only): the matrix is symmetric, so a column
-    // block only visits the row blocks from its own diagonal tile on (weight 1) and counts the tiles
-    // beyond it twice; the workgroup starts at its first column block's diagonal tile.
-    const bool use_sym = EPI >= 1 && EPI <= 3 && sym != 0;
-    const int64_t sym_off = excl_offset / 32;    // block index of kept element 0 on the reduced axis (its diagonal)
-    if (use_sym) {
-        const int64_t gs = sym_off + (int64_t)blockIdx.x * 4 * NCB;
-        if (b0 < gs) b0 = gs;
-    }
-    float wgt[NCB];
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) wgt[cb] = 1.f;
-    auto set_weights = [&](int64_t pblk) {
-        if (use_sym) {
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                const int64_t cbi = sym_off + col0 / 32 + cb;
-                wgt[cb] = pblk > cbi ? 2.f : (pblk == cbi ? 1.f : 0.f);
-            }
-        }
-    };
-
-    // ---- streaming of the reduced-axis operand through LDS -------------------------------------
-    // The four waves of a workgroup sweep the same reduced-axis blocks (each for its own columns), so
-    // they share one three-stage ring in LDS and fill it together with LDS-DMA
-    // (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR staging; each wave brings a quarter
-    // of every chunk).  The fragment-major global layout is lane-linear, which is exactly the image an
-    // LDS-DMA writes, and the later ds_read_b128 of lane l at offset 16*l is conflict-free.
-    // One barrier per chunk: before it every wave drains its own DMAs (vmcnt) of the chunk issued at
-    // the top of this one (two chunks ahead of the one being consumed); after it that chunk is
-    // complete for everybody and the stage just consumed may be overwritten.
-    constexpr int CS = DP < 32 ? DP : 32;     // MFMA steps per ring stage ("chunk")
-    constexpr int CPB = DP / CS;              // chunks per 32-row block
-    constexpr int CQ = CS / 4;                // 1 KiB DMA pieces per chunk
-    constexpr int CHUNK_F = CS * 64;          // floats per chunk
-    constexpr int STAGE_F = CHUNK_F + 64;     // + one 256-B piece holding the block's 32 row biases
-#ifndef LVAE_PF
-#define LVAE_PF 3
-#endif
-    constexpr int PF = LVAE_PF;               // chunks the DMA runs ahead of the MFMAs
-    constexpr int NST = PF + 1;
-    __shared__ __attribute__((aligned(16))) float ring[NST * STAGE_F];
-    // PERM: label fragments of a block are consumed one block after its operand chunks (with the
-    // tile's epilogue), so they live in a ring of their own, deep enough to outlast that delay
-    constexpr int NSTL = 2 + (PF + CPB - 1) / CPB;
-    constexpr int LAB_F = 4 * 2 * 64 * 4;     // floats (= 8 KiB) of label fragments per block
-    __shared__ __attribute__((aligned(16))) float lring[PERM ? NSTL * LAB_F : 4];
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    // global addresses = wave-uniform base (scalar registers) + a constant 32-bit lane offset, so that the
-    // per-chunk address arithmetic stays on the scalar unit
-    const unsigned lane16 = (unsigned)lane * 16u, lane4 = (unsigned)lane * 4u;
-    auto dma_chunk = [&](int64_t blk, int ch, int stage) {
-        const char* g = reinterpret_cast<const char*>(rfrag + (blk * (DP / 4) + ch * CQ) * 256);
-        float* l = ring + stage * STAGE_F;
-#pragma unroll
-        for (int q0 = 0; q0 < CQ; q0 += 4) {
-            const int q = q0 + wave_u;
-            __builtin_amdgcn_global_load_lds((gptr_t)(g + q * 1024 + lane16), (lptr_t)(l + q * 256), 16, 0, 0);
-        }
-        if (ch == 0) { // 64 lanes x 4 B: this block's 32 biases (+32 of the next block, unused); every wave
-                       // writes the same bytes so that all waves have the same DMA count per chunk
-            __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(rbias + blk * 32) + lane4),
-                                             (lptr_t)(l + CHUNK_F), 4, 0, 0);
-            if (PERM) {
-                const float* lg = reinterpret_cast<const float*>(pa.labfrag) + blk * LAB_F + lane * 4;
-                float* ll = lring + (int)((blk - b0) % NSTL) * LAB_F;
-#pragma unroll
-                for (int q0 = 0; q0 < 8; q0 += 4) {
-                    const int q = q0 + wave_u;
-                    __builtin_amdgcn_global_load_lds((gptr_t)(lg + q * 256), (lptr_t)(ll + q * 256), 16, 0, 0);
-                }
-            }
-        }
-    };
-    // chunk index t (counted from this workgroup's first block) -> (block, chunk-in-block), clamped to
-    // the last chunk of the range so that running ahead past the end is a harmless re-read
-    const int t_end = (int)(b1 - b0) * CPB;              // < 2^31: a split holds at most 2^26 blocks
-    auto dma_linear = [&](int t) {
-        if (t >= t_end) t = t_end - 1;
-        dma_chunk(b0 + t / CPB, t % CPB, t % NST);
-    };
-
-    auto mask_diag = [&](f32x16 (&acc)[NCB], int64_t blk) {
-        // drop the pair (reduced row == kept column + offset): only blocks that can contain it
-        const int64_t row_lo = blk * 32;
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
-            const int64_t cbase = col0 + cb * 32 + excl_offset;
-            if (row_lo < cbase + 32 && row_lo + 32 > cbase) {
-                const int64_t want = cbase + r - row_lo;   // row index inside the block
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (want == 8 * g + 4 * h + e) acc[cb][4 * g + e] = (EPI >= 1 && EPI <= 3) ? INFINITY : -INFINITY;
-            }
-        }
-    };
-
-    // Epilogue of one 32x32 tile, cut into EPI_MS micro-slices of <= ~10 VALU instructions so that
-    // each one issues in the shadow of one MFMA of the NEXT block (64 cycles of matrix-pipe time):
-    //   0..7: two exponentials each (packed subtract / add), summed into the tile sum
-    //   8: tile sum -> running sum, or the rare redo against a new maximum.
-    // (EPI 1-3: eight slices of two kernel values each, the ninth folds the tile sum into float64;
-    //  EPI 4: eight slices of two exponentials, nothing else.)
-    constexpr int EPI_MS = EPI == 4 ? 8 : 9;
-    f32x2 m2[NCB], kt2[NCB];            // EPI 0: minus the running max, twice (packed operand); tile sum in flight
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-        m2[cb] = (f32x2){-LSE_MINIT, -LSE_MINIT};
-        kt2[cb] = (f32x2){0.f, 0.f};
-    }
-    float kv[PERM ? 16 : 1];            // PERM: the kernel values of the tile whose epilogue is running
-    // Kernel-sum parameters, read once into (scalar) registers: EPI 1 = one bandwidth (c0 + c1*t),
-    // EPI 2 = polynomial of degree <= 16 in t, fully unrolled Horner (unused high coefficients are 0),
-    // EPI 3 = arbitrary bandwidths, one exponential each.
-    constexpr int KC = EPI == 1 ? 2 : (EPI == 2 ? 17 : (EPI == 3 ? LVAE_KSUM_MAX : 1));
-    float kc[KC];
-    float k_eps = 0.f, k_nbase = 0.f;
-    int k_n = 0;
-    if (EPI >= 1 && EPI <= 3) {
-        const KsumParams* kp = &hdr->ksum;
-        k_eps = kp->eps;
-        k_nbase = kp->nbase;
-        k_n = kp->n;
-#pragma unroll
-        for (int k = 0; k < KC; ++k) kc[k] = kp->c[k];
-    }
-    // two kernel values at a time (packed fp32 for the polynomial)
-    auto kfun2 = [&](float d2a, float d2b) -> f32x2 {
-        const f32x2 v = {fabsf(d2a) + k_eps, fabsf(d2b) + k_eps};
-        if (EPI == 1 || EPI == 2) {
-            const f32x2 a = v * (f32x2){k_nbase, k_nbase};
-            f32x2 t;
-            t.x = lvae_exp2(a.x);
-            t.y = lvae_exp2(a.y);
-            if (EPI == 1) return __builtin_elementwise_fma((f32x2){kc[1], kc[1]}, t, (f32x2){kc[0], kc[0]});
-            f32x2 pacc = {kc[16], kc[16]};
-#pragma unroll
-            for (int k = 15; k >= 0; --k) pacc = __builtin_elementwise_fma(pacc, t, (f32x2){kc[k], kc[k]});
-            return pacc;
-        } else {
-            f32x2 f = {0.f, 0.f};
-#pragma unroll 4
-            for (int k = 0; k < KC; ++k)
-                if (k < k_n) {
-                    f.x += lvae_exp2(v.x * kc[k]);
-                    f.y += lvae_exp2(v.y * kc[k]);
-                }
-            return f;
-        }
-    };
-    auto epi_micro = [&](const f32x16 (&prev)[NCB], int cb, int ms) {
-        if (EPI == 4) {
-            // fixed reference (folded into the row biases by lse_shift_bias_kernel): every term is at
-            // most 2^LSE_HEADROOM, so the tile is two exponentials and one packed add per slice
-            f32x2 e;
-            e.x = lvae_exp2(prev[cb][2 * ms]);
-            e.y = lvae_exp2(prev[cb][2 * ms + 1]);
-            kt2[cb] += e;
-        } else if (EPI >= 1) {
-            if (ms < 8) {
-                const f32x2 kval = kfun2(prev[cb][2 * ms], prev[cb][2 * ms + 1]);
-                if (ms == 0) kt2[cb] = kval;
-                else kt2[cb] += kval;
-                if (PERM) {
-                    kv[2 * ms] = kval.x;
-                    kv[2 * ms + 1] = kval.y;
-                }
-            } else if (PERM) {
-                // strictly-upper (or, without sym, all) tiles and the diagonal tile are kept apart
-                const float ts = kt2[cb].x + kt2[cb].y;
-                if (use_sym && wgt[cb] == 1.f) ksd += (double)ts;
-                else if (!use_sym || wgt[cb] == 2.f) ks[cb] += (double)ts;
-            } else {
-                ks[cb] += (double)((kt2[cb].x + kt2[cb].y) * wgt[cb]);
-            }
-        } else if (ms < 8) {
-            // two pairs per slice on the packed fp32 pipe: subtract the running max, exponentiate,
-            // accumulate the tile sum (the first slice starts it)
-            const f32x2 pr = {prev[cb][2 * ms], prev[cb][2 * ms + 1]};
-            f32x2 x;    // (the compiler would split this packed add into two scalar ones)
-            asm("v_pk_add_f32 %0, %1, %2" : "=v"(x) : "v"(pr), "v"(m2[cb]));
-            f32x2 e;
-            e.x = lvae_exp2(x.x);
-            e.y = lvae_exp2(x.y);
-            if (ms == 0) kt2[cb] = e;
-            else kt2[cb] += e;
-        } else {
-            // Lazy running max without a max tree: all terms are positive, so a tile sum below 2^LSE_THR
-            // proves that no term exceeded the running max by LSE_THR bits and the sum is simply added.
-            // Otherwise (the first tile, or a rare jump of the maximum; inf/NaN land here too) the whole
-            // wave redoes the tile against the true maximum.
-            const float ts = kt2[cb].x + kt2[cb].y;
-            if (__builtin_expect(__any(!(ts < LSE_BIG)), 0)) {
-                float t = prev[cb][0];
-#pragma unroll
-                for (int e = 1; e < 16; ++e) t = fmaxf(t, prev[cb][e]);
-                const float mn = fmaxf(m[cb], t);
-                float acc = s[cb] * lvae_exp2(m[cb] - mn);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc += lvae_exp2(prev[cb][e] - mn);
-                s[cb] = acc;
-                m[cb] = mn;
-                m2[cb] = (f32x2){-mn, -mn};
-            } else {
-                s[cb] += ts;
-            }
-        }
-    };
-    // ---- PERM: label-permutation accumulators --------------------------------------------------
-    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    f32x16 Y[PERM ? 4 : 1];
-    double qacc[PERM ? 4 : 1];
-    double yacc[PERM ? 4 : 1];          // unweighted sums of Y (sym: one half of lr_p)
-    unsigned cmask[PERM ? 4 : 1];       // bit e: label of kept element (accumulator row e) under labeling 32*pt + r
-    unsigned vmask = 0;                 // bit e: accumulator row e is a real kept element (not padding)
-    int pcount = 0;
-    if (PERM) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-            if (col0 + (e & 3) + 8 * (e >> 2) + 4 * h < pa.C) vmask |= 1u << e;
-#pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
-            unsigned mk = 0;
-            const int perm = 32 * pt + r;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t c = col0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (perm < pa.P && c < pa.C && pa.labels[(int64_t)perm * pa.n_lab + pa.col_offset + c]) mk |= 1u << e;
-            }
-            cmask[pt] = mk;
-            qacc[pt] = 0.0;
-            yacc[pt] = 0.0;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) Y[pt][e] = 0.f;
-        }
-    }
-    auto perm_flush = [&](float wv) __attribute__((always_inline)) {
-#pragma unroll
-        for (int pt = 0; pt < (PERM ? 4 : 0); ++pt) {
-            float t = 0.f, u = 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                t += ((cmask[pt] >> e) & 1u) ? Y[pt][e] : 0.f;
-                u += ((vmask >> e) & 1u) ? Y[pt][e] : 0.f;
-                Y[pt][e] = 0.f;
-            }
-            qacc[pt] += (double)(t * wv);
-            yacc[pt] += (double)u;
-        }
-    };
-    // kv (the finished tile, accumulator layout: lane = column, 16 rows) -> two bf16 limbs -> 16 MFMAs
-    // wv: weight of the tile (sym: 0 below the diagonal tile -> nothing to do, 1 on it, 2 beyond; else 1).
-    // A flush never mixes weights: the diagonal tile is flushed on its own.
-    auto perm_tile = [&](int lstage, float wv) __attribute__((always_inline)) {
-        if (wv == 0.f) return;
-        bf16x8 ahi[2], alo[2];
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-            for (int e2 = 0; e2 < 4; ++e2) {
-                const f32x2 v = {kv[8 * sp + 2 * e2], kv[8 * sp + 2 * e2 + 1]};
-                const bf16x2 hh = __builtin_convertvector(v, bf16x2);
-                const f32x2 hf = __builtin_convertvector(hh, f32x2);
-                const bf16x2 ll = __builtin_convertvector(v - hf, bf16x2);
-                ahi[sp][2 * e2] = hh[0];
-                ahi[sp][2 * e2 + 1] = hh[1];
-                alo[sp][2 * e2] = ll[0];
-                alo[sp][2 * e2 + 1] = ll[1];
-            }
-        const bf16x8* lb = reinterpret_cast<const bf16x8*>(lring + lstage * LAB_F);
-#pragma unroll
-        for (int pt = 0; pt < (PERM ? 4 : 0); ++pt)
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-                const bf16x8 b = lb[(pt * 2 + sp) * 64 + lane];
-                Y[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[sp], b, Y[pt], 0, 0, 0);
-                Y[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[sp], b, Y[pt], 0, 0, 0);
-            }
-        if ((use_sym && wv == 1.f) || ++pcount == PERM_FLUSH) {
-            perm_flush(wv);
-            pcount = 0;
-        }
-    };
-
-    constexpr int SLOTS = DP * NCB;                    // MFMAs per block
-    constexpr int MS_TOTAL = EPI_MS * NCB;             // micro-slices per block
-
-    // Values carried from the tail of one chunk into the next: the first 1 KiB piece of the next chunk
-    // and (at a block boundary) the next block's row biases, both already read from LDS.
-    f32x4 a_pre;
-    f32x16 c_pre;
-    auto read_piece = [&](int stage, int q) -> f32x4 {
-        return reinterpret_cast<const f32x4*>(ring + stage * STAGE_F)[q * 64 + lane];
-    };
-    auto read_bias = [&](int stage) {
-        const f32x4* bl = reinterpret_cast<const f32x4*>(ring + stage * STAGE_F + CHUNK_F) + h;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 c = bl[2 * g];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) c_pre[4 * g + e] = c[e];
-        }
-    };
-
-    // One block: keep the ring one chunk ahead, run the DP*NCB MFMAs into `acc` (first step takes the
-    // row biases as its C operand) while the epilogue of `prev` issues in their shadow.  Everything is
-    // pinned in program order (sched_barrier) so the compiler cannot bunch the epilogue up.
-    int t_lin = 0;                                         // chunks consumed so far by this wave
-    auto run_block = [&](f32x16 (&acc)[NCB], const f32x16 (&prev)[NCB], int64_t blk, bool with_epi) {
-        const f32x16 cv = c_pre;
-        if (EPI >= 1 && EPI <= 3) set_weights(blk - 1);
-#pragma unroll
-        for (int ch = 0; ch < CPB; ++ch) {
-            const int stage = t_lin % NST;
-            const int stage_next = (t_lin + 1) % NST;
-#ifndef LVAE_DBG_NODMA   // (ablation builds for DESIGN.md: -DLVAE_DBG_NODMA / -DLVAE_DBG_NOBAR; results are garbage)
-            dma_linear(t_lin + PF);    // into the stage consumed one chunk ago (freed by the last barrier)
-#endif
-            f32x4 a4[2];
-            a4[0] = a_pre;
-#pragma unroll
-            for (int q = 0; q < CQ; ++q) {
-                // The piece read one group ago has had four MFMAs to land: wait for it BEFORE issuing the
-                // next read, otherwise the compiler's own lgkmcnt(0) lands after the new read and stalls
-                // the wave for a full LDS round trip.  (0xC07F = lgkmcnt(0), vmcnt/expcnt untouched.)
-                __builtin_amdgcn_s_waitcnt(0xC07F);
-                if (q + 1 < CQ) {
-                    a4[(q + 1) & 1] = read_piece(stage, q + 1);
-                } else {
-                    // chunk t_lin+1 was certified complete by the barrier that ended chunk t_lin-1
-                    a_pre = read_piece(stage_next, 0);
-                    if (ch == CPB - 1) read_bias(stage_next);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int st = ch * CS + q * 4 + e;
-#pragma unroll
-                    for (int cb = 0; cb < NCB; ++cb) {
-                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q & 1][e], bz[cb][st],
-                                                                       st == 0 ? cv : acc[cb], 0, 0, 0);
-                        const int u = st * NCB + cb;
-                        if (with_epi) {   // micro-slices spread evenly over the block's MFMA slots
-#pragma unroll
-                            for (int k = (u * MS_TOTAL) / SLOTS; k < ((u + 1) * MS_TOTAL) / SLOTS; ++k)
-                                epi_micro(prev, k / EPI_MS, k % EPI_MS);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
-            if (PERM && with_epi && ch == CPB - 1) perm_tile((int)((blk - 1 - b0) % NSTL), wgt[0]);
-            // my pieces of chunk t_lin+2 have landed; after the barrier everybody's have, and
-            // everybody is done reading chunk t_lin's stage
-            // (chunks t_lin+3 .. t_lin+PF, issued later, may stay in flight: counted wait)
-            {
-                constexpr int per_chunk = CQ / 4;
-                int left = 0;
-#pragma unroll
-                for (int k = 3; k <= PF; ++k) left += per_chunk + (((ch + k) % CPB) == 0 ? (PERM ? 3 : 1) : 0);
-                wait_vmcnt(left);
-            }
-#ifndef LVAE_DBG_NOBAR
-            __builtin_amdgcn_s_barrier();
-#endif
-            ++t_lin;
-        }
-        if (EXCL) mask_diag(acc, blk);
-    };
-    auto drain = [&](const f32x16 (&prev)[NCB]) {
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-            for (int ms = 0; ms < EPI_MS; ++ms) epi_micro(prev, cb, ms);
-    };
-
-    f32x16 accA[NCB], accB[NCB];
-    if (b0 < b1) {
-#pragma unroll
-        for (int k = 0; k < PF; ++k) dma_linear(k);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        a_pre = read_piece(0, 0);
-        read_bias(0);
-        run_block(accA, accB, b0, false);
-        int64_t blk = b0 + 1;
-        // two blocks per trip so the accumulator sets swap roles without register copies
-        for (; blk + 1 < b1; blk += 2) {
-            run_block(accB, accA, blk, true);
-            run_block(accA, accB, blk + 1, true);
-        }
-        if (EPI >= 1 && EPI <= 3) set_weights(b1 - 1);
-        if (blk < b1) {
-            run_block(accB, accA, blk, true);
-            set_weights(b1 - 1);
-            drain(accB);
-        } else {
-            drain(accA);
-        }
-        if (PERM) {
-            perm_tile((int)((b1 - 1 - b0) % NSTL), wgt[0]);
-            if (pcount) perm_flush(wgt[0]);
-#pragma unroll
-            for (int pt = 0; pt < 4; ++pt) {
-                const double tot = qacc[pt] + __shfl_xor(qacc[pt], 32, 64);
-                const double ytot = yacc[pt] + __shfl_xor(yacc[pt], 32, 64);
-                if (h == 0 && 32 * pt + r < pa.P) {
-                    atomicAdd(&pa.qperm[32 * pt + r], tot);
-                    if (use_sym) atomicAdd(&pa.qperm[128 + 32 * pt + r], ytot);
-                }
-            }
-        }
-    }
-
-    // merge the two half-waves (same column, complementary rows) and publish
-    if (EPI == 4) {
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
-            const float sv = kt2[cb].x + kt2[cb].y;
-            const float ss = sv + __shfl_xor(sv, 32, 64);
-            if (h == 0) partial[(int64_t)blockIdx.y * cpad + col0 + cb * 32 + r] = make_float2(0.f, ss);
-        }
-        return;
-    }
-    if (EPI >= 1) {
-        double* kpartial = reinterpret_cast<double*>(partial);
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
-            const double tot = ks[cb] + __shfl_xor(ks[cb], 32, 64);
-            if (h == 0) kpartial[(int64_t)blockIdx.y * cpad + col0 + cb * 32 + r] = tot;
-        }
-        if (PERM) {
-            const double dtot = ksd + __shfl_xor(ksd, 32, 64);
-            if (h == 0) pa.diag_partial[(int64_t)blockIdx.y * cpad + col0 + r] = dtot;
-        }
-        return;
-    }
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-        const float mo = __shfl_xor(m[cb], 32, 64);
-        const float so = __shfl_xor(s[cb], 32, 64);
-        const float mm = fmaxf(m[cb], mo);
-        const float ss = s[cb] * lvae_exp2(m[cb] - mm) + so * lvae_exp2(mo - mm);
-        if (h == 0) partial[(int64_t)blockIdx.y * cpad + col0 + cb * 32 + r] = make_float2(mm, ss);
-    }
-}
+// Launchers of the fused pair kernel (pair_lse_kernel.h) on the fp32 matrix cores: the default contraction.
+#include "pair_lse_kernel.h"
 
 template <int DP, int NCB, int WPS>
 static int launch_t(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,

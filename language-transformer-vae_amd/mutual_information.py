@@ -109,7 +109,7 @@ def log_prob_pairs(dists, sample_batch):
     return _spread_pairs(sample_batch.squeeze(), mu, cov, N.SPREAD_VAR)
 
 
-def _bounds(samples, dists):
+def _bounds(samples, dists, path=N.PATH_AUTO):
     mu, cov = _dists_to_params(dists)
     z, mu, cov = N.as_f32(samples.squeeze(), "samples"), N.as_f32(mu, "mu"), N.as_f32(cov, "cov")
     K, D = z.shape
@@ -119,7 +119,7 @@ def _bounds(samples, dists):
         N.check(N.lib().lvae_pair_bounds_workspace_bytes(K, D, nbytes))
         ws = N.workspace(nbytes.value, dev)
         out = torch.empty(2, dtype=torch.float64, device=dev)
-        N.check(N.lib().lvae_pair_bounds_f32(N.ptr(z), N.ptr(mu), N.ptr(cov), K, D, N.PATH_AUTO, N.ptr(out),
+        N.check(N.lib().lvae_pair_bounds_f32(N.ptr(z), N.ptr(mu), N.ptr(cov), K, D, path, N.ptr(out),
                                              N.ptr(ws), nbytes.value, N.stream_ptr(dev)))
     return out
 

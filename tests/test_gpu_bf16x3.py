@@ -94,3 +94,79 @@ def test_bf16x3_rejects_what_it_does_not_cover():
     mu = torch.zeros(64, 100, device="cuda")
     with pytest.raises(N.LvaeError, match="bf16x3"):
         E.approximate_log_q_z(mu, mu, mu, method="all", prod_marginals=False, reduce_mean=False, path=BX)
+    with pytest.raises(N.LvaeError, match="pair math"):
+        N.set_pair_math(7)
+    assert N.get_pair_math() == N.MATH_FP32
+
+
+def test_bf16x3_mi_bounds_with_excluded_diagonal():
+    """The MBU bound masks the diagonal out of the logsumexp (mutual_information.py:207): same golden vectors,
+    the split-bf16 kernel with the exclusion folded into the bias operand."""
+    from lvae import mutual_information as MI
+    for case in ("k128", "k16"):
+        g = load_golden("mi_bounds_" + case)
+        z, mulv = dev(g["z"]), dev(g["mu_logvars"])
+        D = g["mu_logvars"].shape[1] // 2
+        mu, std = mulv[:, :D].contiguous(), torch.exp(0.5 * mulv[:, D:]).contiguous()
+        lower, upper = MI._bounds(z, (mu, std), path=BX).tolist()
+        assert abs(lower - float(g["lower"])) <= 1e-4 * abs(float(g["lower"]))
+        assert abs(upper - float(g["upper"])) <= 1e-4 * abs(float(g["upper"]))
+    rng = np.random.default_rng(3)
+    K, D = 1500, 32
+    mu = rng.standard_normal((K, D)).astype(np.float32)
+    lv = (0.5 * rng.standard_normal((K, D)) - 1).astype(np.float32)
+    z = (mu + rng.standard_normal((K, D)).astype(np.float32) * np.exp(0.25 * lv)).astype(np.float32)
+    lo, up = onp.calc_upper_and_lower_bound_representational_mi(z, np.concatenate([mu, lv], 1))
+    glo, gup = MI._bounds(dev(z), (dev(mu), dev(np.exp(0.5 * lv))), path=BX).tolist()
+    assert abs(glo - lo) <= 1e-4 * abs(lo) and abs(gup - up) <= 1e-4 * abs(up)
+
+
+# ---- the kernel-sum / MMD entry points under lvae_set_pair_math(LVAE_MATH_BF16X3) -------------------------
+# The same tests as for the fp32 contraction (same oracle, same tolerances), run with the process-wide mode set.
+import test_gpu_misc as TM     # noqa: E402
+
+
+@pytest.fixture
+def bf16x3_math():
+    from lvae import _native as N
+    with N.pair_math(N.MATH_BF16X3):
+        assert N.get_pair_math() == N.MATH_BF16X3
+        yield
+    assert N.get_pair_math() == N.MATH_FP32
+
+
+@pytest.mark.parametrize("case", ["n256", "n100_d64"])
+def test_bf16x3_biased_mmd(case, bf16x3_math):
+    TM.test_biased_mmd(case)
+
+
+@pytest.mark.parametrize("n1,n2,D", [(300, 300, 32), (257, 190, 64), (1000, 1200, 32)])
+def test_bf16x3_tts_mmd(n1, n2, D, bf16x3_math):
+    TM.test_tts_mmd_unpinned(n1, n2, D)
+
+
+@pytest.mark.parametrize("na,nb,D,off", [(300, 500, 32, 120), (257, 257, 64, 0), (90, 700, 16, -10), (130, 64, 128, 40)])
+def test_bf16x3_kernel_sum_blocks(na, nb, D, off, bf16x3_math):
+    TM.test_kernel_sum_blocks(na, nb, D, off)           # (D = 128 stays on the fp32 contraction)
+
+
+@pytest.mark.parametrize("n1,n2,D,P", [(300, 340, 32, 20), (257, 190, 64, 130), (1000, 1500, 16, 9), (2048, 2048, 32, 33)])
+def test_bf16x3_mmd_permutation_test(n1, n2, D, P, bf16x3_math):
+    TM.test_mmd_permutation_test_unpinned(n1, n2, D, P)
+
+
+def test_bf16x3_mmd_full_size_properties(bf16x3_math):
+    TM.test_mmd_full_size_properties()
+
+
+def test_bf16x3_mmd_is_a_different_kernel_with_the_same_answer():
+    from lvae import _native as N
+    from lvae.two_sample import MMDStatistic
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.randn(8192, 32, device="cuda", generator=g)
+    y = torch.randn(8192, 32, device="cuda", generator=g) * 1.05
+    alphas = [0.1 * i for i in range(15)]
+    a = float(MMDStatistic(8192, 8192)(x, y, alphas))
+    with N.pair_math(N.MATH_BF16X3):
+        b = float(MMDStatistic(8192, 8192)(x, y, alphas))
+    assert abs(a - b) <= 2e-6 * 15

@@ -29,5 +29,10 @@ def run(n1, n2, D, P, iters=2):
           flush=True)
 
 if __name__ == "__main__":
+    # LVAE_PAIR_MATH=bf16x3: the experimental split-bf16 contraction (lvae_set_pair_math)
+    from lvae import _native as N
+    if os.environ.get("LVAE_PAIR_MATH") == "bf16x3":
+        N.set_pair_math(N.MATH_BF16X3)
+        print("pair math: bf16x3", flush=True)
     for a in sys.argv[1:]:
         run(*(int(v) for v in a.split(",")))
