@@ -109,6 +109,16 @@ int lvae_log_qz_partial_f32(const float* z, const float* mu, const float* spread
                             float* row_max, float* row_sum,
                             void* ws, int64_t ws_bytes, void* stream);
 
+/* Merge of partial logsumexps over disjoint sets of posteriors (the pairs lvae_log_qz_partial_f32 writes):
+ * (max, sum) = (max_a, sum_a) (+) (max_b, sum_b), written to out_max / out_sum (renormalised so that the sum
+ * lies in [1, 2)), and / or the finished log_qz[i] = max + log(sum) - log_norm.  max_b / sum_b may be NULL
+ * (finalise one partial).  In-place use (out_* aliasing an input pair) is allowed.  No counterpart in the
+ * reference; used to overlap the all-gather of posterior parameters with the local block of the pair matrix
+ * (distributed.sharded_latent_stats). */
+int lvae_lse_combine_f32(const float* max_a, const float* sum_a, const float* max_b, const float* sum_b,
+                         int64_t n, float log_norm, float* out_log_qz, float* out_max, float* out_sum,
+                         void* stream);
+
 /* q_z_estimate (mutual_information.py:44-52) including quirk Q2: the reduction runs over the SAMPLE
  * axis:  out[j] = LSE_i log N(z_i; mu_j, var_j) - log_norm,  out [N].  Workspace: query with the
  * roles swapped, lvae_log_qz_workspace_bytes(N, M, D, 0, ..). */

@@ -95,6 +95,8 @@ int lvae_launch_reparam_bwd(const float* logvar, const float* eps, const float* 
 int lvae_launch_kl_bwd(const float* mu, const float* logvar, const float* g_kl, const float* g_hinge,
                        int row_mode, int64_t n, int D, float lambda, float* d_mu, float* d_logvar,
                        hipStream_t st);
+int lvae_launch_lse_combine(const float* max_a, const float* sum_a, const float* max_b, const float* sum_b,
+                            int64_t n, float log_norm, float* out, float* out_max, float* out_sum, hipStream_t st);
 size_t lvae_cat_bounds_workspace(int64_t K);
 int lvae_launch_cat_bounds(const float* probs, const int64_t* samples, int64_t K, int64_t V, double* out, void* ws,
                            hipStream_t st);
@@ -511,6 +513,18 @@ extern "C" int lvae_log_qz_partial_f32(const float* z, const float* mu, const fl
     LVAE_CHECK_ARG(row_max && row_sum, "row_max and row_sum must be non-NULL");
     return run_log_qz(z, mu, spread, spread_kind, M, N, D, 0.f, 0, 0, path, nullptr, nullptr, row_max,
                       row_sum, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int lvae_lse_combine_f32(const float* max_a, const float* sum_a, const float* max_b,
+                                    const float* sum_b, int64_t n, float log_norm, float* out_log_qz,
+                                    float* out_max, float* out_sum, void* stream) {
+    LVAE_CHECK_ARG(max_a && sum_a, "max_a and sum_a must be non-NULL");
+    LVAE_CHECK_ARG((max_b == nullptr) == (sum_b == nullptr), "max_b and sum_b come together");
+    LVAE_CHECK_ARG((out_max == nullptr) == (out_sum == nullptr), "out_max and out_sum come together");
+    LVAE_CHECK_ARG(out_log_qz || out_max, "nothing to write");
+    LVAE_CHECK_ARG(n >= 1, "need n >= 1");
+    return lvae_launch_lse_combine(max_a, sum_a, max_b, sum_b, n, log_norm, out_log_qz, out_max, out_sum,
+                                   (hipStream_t)stream);
 }
 
 // Roles swapped: posteriors on the kept axis (one output each), samples on the reduced axis.

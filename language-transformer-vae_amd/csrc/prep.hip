@@ -413,3 +413,38 @@ int lvae_launch_ksum_columns(const double* partial, int nsplit, int64_t cpad, in
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }
+
+// Merge of two partial logsumexps over disjoint sets of posteriors (natural-log domain, the (row_max,
+// row_sum) pairs of lvae_log_qz_partial_f32):  m = max(ma, mb), s = sa e^(ma - m) + sb e^(mb - m).
+// b may be absent (finalisation of a single partial).  The rescaled sums are formed in float64: a sum may be
+// as large as N * 2^100 when its reference is the fixed one.
+__global__ void __launch_bounds__(256)
+lse_combine_kernel(const float* __restrict__ max_a, const float* __restrict__ sum_a,
+                   const float* __restrict__ max_b, const float* __restrict__ sum_b, int64_t n, float log_norm,
+                   float* __restrict__ out, float* __restrict__ out_max, float* __restrict__ out_sum) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float ma = max_a[i];
+    const float mb = max_b ? max_b[i] : -INFINITY;
+    const float m = fmaxf(ma, mb);
+    double s = 0.0;
+    if (sum_a[i] > 0.f) s += (double)sum_a[i] * exp((double)ma - (double)m);
+    if (max_b && sum_b[i] > 0.f) s += (double)sum_b[i] * exp((double)mb - (double)m);
+    // keep the pair in float range: renormalise the sum into [1, 2) * 2^k with the exponent folded into the max
+    int e = 0;
+    const double fr = frexp(s, &e);                  // s = fr * 2^e, fr in [0.5, 1)
+    const double mm = (double)m + (double)(e - 1) * 0.6931471805599453;
+    if (out) out[i] = (float)((double)m + log(s) - (double)log_norm);
+    if (out_max) {
+        out_max[i] = (float)mm;
+        out_sum[i] = (float)(fr * 2.0);
+    }
+}
+
+int lvae_launch_lse_combine(const float* max_a, const float* sum_a, const float* max_b, const float* sum_b,
+                            int64_t n, float log_norm, float* out, float* out_max, float* out_sum, hipStream_t st) {
+    hipLaunchKernelGGL(lse_combine_kernel, dim3((unsigned)lvae_ceil_div(n, 256)), dim3(256), 0, st, max_a, sum_a,
+                       max_b, sum_b, n, log_norm, out, out_max, out_sum);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}

@@ -97,8 +97,65 @@ def hip_local_stats(mu_all, logvar_all, z_local, mu_local, logvar_local, log_nor
     return sums, log_q_z
 
 
+class HipBlockKernels:
+    """The three per-rank device steps of the overlapped exchange on the HIP path (the CPU tests inject an
+    oracle-backed object with the same three methods to exercise the collective logic)."""
+
+    @staticmethod
+    def partial(mu, logvar, z):
+        from . import estimators as E
+        return E.log_qz_partial(mu, logvar, z)
+
+    @staticmethod
+    def combine(own, rest, log_norm):
+        from . import estimators as E
+        return E.lse_combine(own, rest, log_norm)
+
+    @staticmethod
+    def sums(z_local, mu_local, logvar_local, log_q_z):
+        from . import _native as N
+        z, mu, lv = (N.as_f32(t, n) for t, n in ((z_local, "z"), (mu_local, "mu"), (logvar_local, "logvar")))
+        dev = z.device
+        with torch.cuda.device(dev):
+            sums = torch.empty(5, dtype=torch.float64, device=dev)
+            N.check(N.lib().lvae_latent_sums_f32(N.ptr(z), N.ptr(mu), N.ptr(lv), N.ptr(log_q_z), None, z.shape[0],
+                                                 z.shape[1], N.ptr(sums), N.stream_ptr(dev)))
+        return sums
+
+
+def overlapped_stats(packed_local, z_local, mu_local, logvar_local, group, log_norm_of, kernels=HipBlockKernels):
+    """The exchange step with the all-gather hidden behind compute (equal shard sizes, joint density only).
+    The logsumexp over posteriors is order-free, so it is evaluated in two blocks:
+      1. the all-gather of the packed [n_r, 2D] parameters is started asynchronously (RCCL runs it on its own
+         stream; with the host-staged gloo rehearsal of GPU tensors it simply runs first);
+      2. meanwhile this rank's samples are contracted against its OWN posteriors (1/world of the pairs) into a
+         partial logsumexp (lvae_log_qz_partial_f32);
+      3. the current stream waits for the collective; the same samples go against all OTHER posteriors (one
+         contiguous copy of the two ranges around the own shard), and the two partials are merged
+         (lvae_lse_combine_f32).
+    Returns (sums [5] float64, log_q_z of the local rows, n_total)."""
+    ws, rank = dist.get_world_size(group), dist.get_rank(group)
+    n_r, D = mu_local.shape
+    gathered = torch.empty((ws * n_r, 2 * D), dtype=packed_local.dtype, device=packed_local.device)
+    work = None
+    if packed_local.is_cuda and _host_staged(group):
+        _all_gather_into(gathered, packed_local, group)
+    else:
+        work = dist.all_gather_into_tensor(gathered, packed_local, group=group, async_op=True)
+    own = kernels.partial(mu_local, logvar_local, z_local)
+    if work is not None:
+        work.wait()                      # GPU: the current stream waits for the collective, the host does not
+    lo, hi = rank * n_r, (rank + 1) * n_r
+    others = torch.cat([gathered[:lo], gathered[hi:]], dim=0)
+    n_total = ws * n_r
+    rest = kernels.partial(others[:, :D].contiguous(), others[:, D:].contiguous(), z_local) if others.shape[0] else None
+    log_q_z = kernels.combine(own, rest, log_norm_of(n_total))
+    return kernels.sums(z_local, mu_local, logvar_local, log_q_z), log_q_z, n_total
+
+
 def sharded_latent_stats(mu_local, logvar_local, z_local, method="all", dataset_size=None,
-                         prod_marginals=False, group=None, local_stats=hip_local_stats, counts=None):
+                         prod_marginals=False, group=None, local_stats=hip_local_stats, counts=None,
+                         overlap=None, block_kernels=HipBlockKernels):
     """Marginal KL / MI (/ TC, dimension-wise KL) over posteriors and samples sharded by rows.
 
     mu_local, logvar_local, z_local: this rank's [n_r, D] rows (z_i drawn from posterior i).
@@ -106,19 +163,35 @@ def sharded_latent_stats(mu_local, logvar_local, z_local, method="all", dataset_
     loss_and_optimisation.py:816-824: mi = E[log q(z|x)] - E[log q(z)], marginal_kl = E[log q(z)] -
     E[log p(z)], tc = E[log q(z)] - E[log prod q(z_d)], dim_kl = E[log prod q(z_d)] - E[log p(z)];
     plus ``log_q_z_local`` (this rank's per-sample vector, left sharded).  ``counts``: rows per rank if
-    known (skips the size exchange)."""
+    known (skips the size exchange).  ``overlap`` (default: whenever it applies -- the HIP path, equal
+    shard sizes known through ``counts``, no prod-marginals, more than one rank): hide the all-gather behind
+    the local block of the pair matrix, see ``overlapped_stats``."""
     packed = torch.cat([mu_local, logvar_local], dim=1).contiguous()
-    gathered, _ = all_gather_rows(packed, group, counts)
-    D = mu_local.shape[1]
-    mu_all, logvar_all = gathered[:, :D].contiguous(), gathered[:, D:].contiguous()
-    n_total = mu_all.shape[0]
     if method == "chen":
         assert dataset_size is not None
-        log_norm = math.log(n_total * dataset_size)
+
+    def log_norm_of(n_total):
+        return math.log(n_total * dataset_size) if method == "chen" else math.log(n_total)
+
+    hip_path = local_stats is hip_local_stats or block_kernels is not HipBlockKernels
+    can_overlap = (hip_path and not prod_marginals and counts is not None
+                   and dist.get_world_size(group) > 1 and len(set(int(c) for c in counts)) == 1
+                   and int(counts[0]) == mu_local.shape[0] and mu_local.shape[0] > 0)
+    if overlap is None:
+        overlap = can_overlap
+    if overlap:
+        if not can_overlap:
+            raise ValueError("overlap=True needs the HIP path, equal shard sizes given by `counts`, "
+                             "prod_marginals=False and world_size > 1")
+        sums, log_q_z, n_total = overlapped_stats(packed, z_local, mu_local, logvar_local, group, log_norm_of,
+                                                  block_kernels)
     else:
-        log_norm = math.log(n_total)
-    sums, log_q_z = local_stats(mu_all, logvar_all, z_local, mu_local, logvar_local, log_norm,
-                                prod_marginals)
+        gathered, _ = all_gather_rows(packed, group, counts)
+        D = mu_local.shape[1]
+        mu_all, logvar_all = gathered[:, :D].contiguous(), gathered[:, D:].contiguous()
+        n_total = mu_all.shape[0]
+        sums, log_q_z = local_stats(mu_all, logvar_all, z_local, mu_local, logvar_local, log_norm_of(n_total),
+                                    prod_marginals)
     sums = sums.to(torch.float64).contiguous()
     _all_reduce(sums, dist.ReduceOp.SUM, group)
     s_lq, s_pm, s_lp, s_lqx, cnt = sums.tolist()

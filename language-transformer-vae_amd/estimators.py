@@ -38,6 +38,46 @@ def log_qz_raw(mu, spread, latent_z, log_norm, prod_marginals=False, spread_kind
     return out, out_pm
 
 
+def log_qz_partial(mu, spread, latent_z, spread_kind=N.SPREAD_LOGVAR, path=N.PATH_AUTO):
+    """Partial logsumexp of ``latent_z`` [M, D] over the given SUBSET of posteriors [n, D]
+    (lvae_log_qz_partial_f32): (row_max, row_sum), natural-log domain, log q = row_max + log(row_sum) - log N
+    once every subset has been merged with ``lse_combine``."""
+    mu, spread, z = N.as_f32(mu, "mu"), N.as_f32(spread, "logvar"), N.as_f32(latent_z, "latent_z")
+    if mu.dim() != 2 or z.dim() != 2 or mu.shape != spread.shape or mu.shape[1] != z.shape[1]:
+        raise ValueError(f"shape mismatch: mu {tuple(mu.shape)}, logvar {tuple(spread.shape)}, "
+                         f"latent_z {tuple(z.shape)}")
+    Nn, D = mu.shape
+    M = z.shape[0]
+    dev = z.device
+    with torch.cuda.device(dev):
+        ws, nbytes = _pair_workspace(M, Nn, D, False, dev)
+        row_max = torch.empty(M, dtype=torch.float32, device=dev)
+        row_sum = torch.empty(M, dtype=torch.float32, device=dev)
+        N.check(N.lib().lvae_log_qz_partial_f32(N.ptr(z), N.ptr(mu), N.ptr(spread), spread_kind, M, Nn, D, path,
+                                                N.ptr(row_max), N.ptr(row_sum), N.ptr(ws), nbytes,
+                                                N.stream_ptr(dev)))
+    return row_max, row_sum
+
+
+def lse_combine(a, b=None, log_norm=None):
+    """Merge two partial logsumexps (pairs from ``log_qz_partial``).  With ``log_norm`` the finished
+    log q(z) = max + log(sum) - log_norm is returned, otherwise the merged (max, sum) pair."""
+    ma, sa = (N.as_f32(t, "partial") for t in a)
+    mb, sb = (N.as_f32(t, "partial") for t in b) if b is not None else (None, None)
+    n = ma.numel()
+    dev = ma.device
+    with torch.cuda.device(dev):
+        if log_norm is not None:
+            out = torch.empty(n, dtype=torch.float32, device=dev)
+            N.check(N.lib().lvae_lse_combine_f32(N.ptr(ma), N.ptr(sa), N.ptr(mb), N.ptr(sb), n, float(log_norm),
+                                                 N.ptr(out), None, None, N.stream_ptr(dev)))
+            return out
+        om, os_ = torch.empty_like(ma), torch.empty_like(sa)
+        N.check(N.lib().lvae_lse_combine_f32(N.ptr(ma), N.ptr(sa), N.ptr(mb), N.ptr(sb), n, 0.0, None,
+                                             N.ptr(om), N.ptr(os_), N.stream_ptr(dev)))
+    return om, os_
+
+
 class _LogQz(torch.autograd.Function):
     """log q(z) / prod-marginals with a HIP backward (lvae_log_qz_bwd_f32): the softmax weights are
     recomputed from the saved forward result, like the forward nothing of size M x N is stored."""

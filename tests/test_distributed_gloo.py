@@ -244,3 +244,88 @@ def test_sharded_mmd_permutation_world2():
         np.testing.assert_allclose(out["statistics"], ref[1:], rtol=1e-8, atol=1e-11)
         assert abs(out["pval"] - float((ref[1:] >= ref[0]).mean())) < 1e-12
     assert results[0][1] == results[1][1]
+
+
+class _OracleBlockKernels:
+    """CPU stand-in for distributed.HipBlockKernels (NumPy float64): partial logsumexp over a subset of
+    posteriors, the merge of two partials, and the five float64 sums."""
+
+    @staticmethod
+    def partial(mu, logvar, z):
+        from oracle import oracle_np as onp
+        dens = onp.log_prob_pairs(z.numpy(), mu.numpy(), np.exp(logvar.numpy().astype(np.float64)))   # [cols, rows]
+        m = dens.max(0)
+        return torch.from_numpy(m), torch.from_numpy(np.exp(dens - m[None]).sum(0))
+
+    @staticmethod
+    def combine(own, rest, log_norm):
+        m, s = own[0].numpy(), own[1].numpy()
+        if rest is not None:
+            m2, s2 = rest[0].numpy(), rest[1].numpy()
+            mm = np.maximum(m, m2)
+            s = s * np.exp(m - mm) + s2 * np.exp(m2 - mm)
+            m = mm
+        return torch.from_numpy(m + np.log(s) - log_norm)
+
+    @staticmethod
+    def sums(z_local, mu_local, logvar_local, log_q_z):
+        from oracle import oracle_np as onp
+        z = z_local.numpy()
+        lp = onp.sample_log_likelihood(z, reduce_batch_dim=False)
+        lqx = onp.sample_log_likelihood(z, mu_local.numpy(), logvar_local.numpy(), reduce_batch_dim=False)
+        return torch.tensor([float(log_q_z.sum()), 0.0, lp.sum(), lqx.sum(), float(len(z))], dtype=torch.float64)
+
+
+def _overlap_worker(rank, world, port, n, D, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lvae import distributed as LD
+    rng = np.random.default_rng(1)
+    mu = rng.standard_normal((n, D)).astype(np.float32)
+    lv = (0.5 * rng.standard_normal((n, D)) - 1).astype(np.float32)
+    z = (mu + rng.standard_normal((n, D)).astype(np.float32) * np.exp(0.5 * lv)).astype(np.float32)
+    lo, hi = LD.shard_bounds(n, world, rank)
+    t = lambda a: torch.from_numpy(a[lo:hi].copy())
+    counts = [n // world] * world
+    plain = LD.sharded_latent_stats(t(mu), t(lv), t(z), method="all", local_stats=_oracle_local_stats, counts=counts)
+    over = LD.sharded_latent_stats(t(mu), t(lv), t(z), method="all", counts=counts, overlap=True,
+                                   block_kernels=_OracleBlockKernels)
+    auto = LD.sharded_latent_stats(t(mu), t(lv), t(z), method="chen", dataset_size=500, counts=counts,
+                                   block_kernels=_OracleBlockKernels)                 # overlap chosen by default
+    err = None
+    try:
+        LD.sharded_latent_stats(t(mu), t(lv), t(z), prod_marginals=True, counts=counts, overlap=True,
+                                block_kernels=_OracleBlockKernels)
+    except ValueError as e:
+        err = str(e)
+    if rank == 0:
+        q.put({"plain": {k: v for k, v in plain.items() if isinstance(v, float)},
+               "over": {k: v for k, v in over.items() if isinstance(v, float)},
+               "auto_marginal_kl": auto["marginal_kl"], "lq_plain": plain["log_q_z_local"].numpy(),
+               "lq_over": over["log_q_z_local"].numpy(), "err": err})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_overlapped_exchange_matches_plain(world):
+    """The all-gather hidden behind the local block (own posteriors first, the others after the wait, partial
+    logsumexps merged) gives the same statistics as gather-then-compute, for every rank position."""
+    n, D = 96 * world, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, n, D, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k, v in res["plain"].items():
+        assert abs(res["over"][k] - v) <= 1e-9 * max(1.0, abs(v)), k
+    np.testing.assert_allclose(res["lq_over"], res["lq_plain"], rtol=1e-10, atol=1e-10)
+    assert abs(res["auto_marginal_kl"] - (res["plain"]["marginal_kl"] - math.log(500))) < 1e-9
+    assert res["err"] and "overlap=True needs" in res["err"]

@@ -183,3 +183,38 @@ def test_translation_and_permutation_invariance():
     # and the sample under its own posterior bounds the mixture from below: log q(z_i) >= log q(z_i|x_i) - log N
     own = E.sample_log_likelihood(z, mu[:M_].contiguous(), lv[:M_].contiguous(), reduce_batch_dim=False)
     assert bool((base >= own - np.log(N_) - 1e-3).all())
+
+
+def test_partial_logsumexp_blocks_merge_to_the_full_result():
+    """lvae_log_qz_partial_f32 over disjoint blocks of posteriors + lvae_lse_combine_f32 (the pieces behind the
+    overlapped multi-GPU exchange and the column-sharded variant) against the one-call result and the oracle.
+    Covers blocks that take different branches: a well-behaved block, a block far from the samples (its
+    fixed-reference pass underflows and is redone), and a block of peaked posteriors (direct path under AUTO)."""
+    from lvae import estimators as E
+    rng = np.random.default_rng(21)
+    N_, M_, D = 1100, 700, 32
+    mu = rng.standard_normal((N_, D)).astype(np.float32)
+    logvar = (0.4 * rng.standard_normal((N_, D)) - 1.0).astype(np.float32)
+    mu[400:650] += 30.0                              # far block
+    logvar[650:700] = -12.0                          # peaked block
+    z = (mu[rng.integers(0, 400, M_)] + 0.5 * rng.standard_normal((M_, D))).astype(np.float32)
+    ref, _ = onp.approximate_log_q_z(mu, logvar, z, method="all", prod_marginals=False, reduce_mean=False)
+    full, _ = E.approximate_log_q_z(dev(mu), dev(logvar), dev(z), method="all", prod_marginals=False,
+                                    reduce_mean=False)
+    np.testing.assert_allclose(full.cpu().numpy(), ref, rtol=1e-4, atol=1e-3)
+    for bounds in ((0, 400, 650, 700, 1100), (0, 1, 1100), (0, 1100)):
+        acc = None
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            part = E.log_qz_partial(dev(mu[lo:hi]), dev(logvar[lo:hi]), dev(z))
+            acc = part if acc is None else E.lse_combine(acc, part)
+        got = E.lse_combine(acc, None, np.log(N_))
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-3, err_msg=str(bounds))
+        np.testing.assert_allclose(got.cpu().numpy(), full.cpu().numpy(), rtol=0, atol=2e-4, err_msg=str(bounds))
+    # the merged pair is kept normalised (sum in [1, 2)) so that chains of merges stay in float range
+    m, s = acc
+    assert float(s.min()) >= 1.0 and float(s.max()) < 2.0
+    # two-block form used by distributed.overlapped_stats
+    own = E.log_qz_partial(dev(mu[:275]), dev(logvar[:275]), dev(z))
+    rest = E.log_qz_partial(dev(mu[275:]), dev(logvar[275:]), dev(z))
+    two = E.lse_combine(own, rest, np.log(N_))
+    np.testing.assert_allclose(two.cpu().numpy(), ref, rtol=1e-4, atol=1e-3)
