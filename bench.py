@@ -125,6 +125,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Untimed prelude before the W warm-up steps: the GPU clock needs ~8 launches (35 ms) of this kernel to ramp
+    # from idle (4.8 ms for the first launch, 4.04 ms in steady state); reported as "clock_ramp_steps".
+    RAMP = 10
+    for _ in range(RAMP):
+        step()
     for _ in range(args.warmup):
         step()
     fence()
@@ -158,7 +163,8 @@ def main():
                 traffic = json.load(f).get("pair_lse_mfma_kernel_hbm_bytes_per_launch")
         line = {
             "metric": "log q(z|x) pair-evals/sec at D=32", "value": value, "unit": "pair-evals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_ramp_steps": RAMP,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: aggregate-posterior log q(z) matrix + logsumexp "

@@ -52,12 +52,15 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ m
     }
 }
 
-// One thread per (row, 4 consecutive dimensions); a block covers 32 rows (= one fragment block).
+// One thread per (row, 4 consecutive dimensions), dimension-fastest: the DP/4 threads of a row are consecutive
+// lanes of one wave, so a row is read with coalesced 16-byte loads and reduced with shuffles; a workgroup
+// covers PREP_RB consecutive 32-row blocks (= fragment blocks) and issues one set of header atomics.
 // SRC 0 (GAUSS): rows from (mu, spread); SRC 1 (SAMPLE): rows from z -> (z^2, z);
 // SRC 2 (POINT): rows from y -> (1, -2y) with bias |y|^2, so that the contraction with a SAMPLE operand
 // is the squared distance |x - y|^2 (kernel-matrix sums; padded rows get +inf).  FRAG selects the fragment-major
-// reduced-axis layout (threads ordered row-fastest so that each wave stores whole 512-B runs),
-// otherwise row-major [row][2*DP] for the kept axis (threads ordered dimension-fastest).
+// reduced-axis layout (the 32 rows of a block at one q are 512 contiguous bytes; a wave writes 128-byte runs),
+// otherwise row-major [row][2*DP] for the kept axis.  `out` may be NULL (bias / header statistics only).
+#define PREP_RB 4
 template <int SRC, bool FRAG>
 __global__ void __launch_bounds__(1024)
 prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ spread, int spread_kind,
@@ -67,106 +70,125 @@ prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ sprea
     constexpr bool GAUSS = SRC == 0;
     constexpr bool POINT = SRC == 2;
     __shared__ float sm_shift[128];
-    __shared__ float sm_c[1024];
-    __shared__ float sm_k[1024];
-    __shared__ float sm_n[1024];
-    const int NQ = DP >> 2;
+    __shared__ float sm_w[16][3];
+    const int NQ = DP >> 2;                    // 4, 8, 16 or 32 lanes per row
     const int tid = threadIdx.x;
     if (tid < DP) sm_shift[tid] = tid < D ? (float)(hdr->colsum[tid] * inv_ngauss) : 0.f;
     __syncthreads();
-    const int r = FRAG ? (tid & 31) : (tid / NQ);
-    const int q = FRAG ? (tid >> 5) : (tid % NQ);
-    const int64_t blk = blockIdx.x;
-    const int64_t row = blk * 32 + r;
-    const bool valid = row < n;
-    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-    float csum = 0.f, cond = 0.f, nsum = 0.f;
-    if (valid) {
+    const int r = tid / NQ;
+    const int q = tid % NQ;
+    const bool vec = (D & 3) == 0 && 4 * q + 4 <= D;
+    float cond_max = 0.f, norm_max = -INFINITY, norm_acc = 0.f;
+    for (int it = 0; it < PREP_RB; ++it) {
+        const int64_t blk = (int64_t)blockIdx.x * PREP_RB + it;
+        if (blk * 32 >= npad) break;
+        const int64_t row = blk * 32 + r;
+        const bool valid = row < n;
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        float csum = 0.f, cond = 0.f, nsum = 0.f;
+        if (valid) {
+            f32x4 xv4 = {0.f, 0.f, 0.f, 0.f}, sp4 = xv4;
+            if (vec) {
+                xv4 = *reinterpret_cast<const f32x4*>(x + row * D + 4 * q);
+                if (GAUSS) sp4 = *reinterpret_cast<const f32x4*>(spread + row * D + 4 * q);
+            } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int d = 4 * q + e;
-            if (d < D) {
-                const float xv = x[row * D + d];
-                const float xs = xv - sm_shift[d];
-                if (GAUSS) {
-                    const float sp = spread[row * D + d];
-                    const float logvar = spread_kind == LVAE_SPREAD_VAR ? logf(sp) : sp;
-                    const float p = spread_kind == LVAE_SPREAD_VAR ? 1.0f / sp : expf(-sp);
-                    v0[e] = -0.5f * LVAE_LOG2E * p;
-                    v1[e] = LVAE_LOG2E * xs * p;
-                    csum += xs * xs * p + logvar + LVAE_LOG_2PI;
-                    nsum += logvar + LVAE_LOG_2PI;
-                    const float t = 2.0f * fabsf(xs) * sqrtf(p) + 3.0f;
-                    cond += 0.5f * t * t;
-                    if (dparams) {
-                        dparams[(row * 3 + 0) * DC + d] = xv;
-                        dparams[(row * 3 + 1) * DC + d] = sqrtf(0.5f * LVAE_LOG2E * p);
-                        dparams[(row * 3 + 2) * DC + d] = -0.5f * LVAE_LOG2E * (logvar + LVAE_LOG_2PI);
+                for (int e = 0; e < 4; ++e)
+                    if (4 * q + e < D) {
+                        xv4[e] = x[row * D + 4 * q + e];
+                        if (GAUSS) sp4[e] = spread[row * D + 4 * q + e];
                     }
-                } else if (POINT) {
-                    v0[e] = 1.0f;
-                    v1[e] = -2.0f * xs;
-                    csum += xs * xs;
-                } else {
-                    v0[e] = xs * xs;
-                    v1[e] = xs;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int d = 4 * q + e;
+                if (d < D) {
+                    const float xv = xv4[e];
+                    const float xs = xv - sm_shift[d];
+                    if (GAUSS) {
+                        const float sp = sp4[e];
+                        const float logvar = spread_kind == LVAE_SPREAD_VAR ? logf(sp) : sp;
+                        const float p = spread_kind == LVAE_SPREAD_VAR ? 1.0f / sp : expf(-sp);
+                        v0[e] = -0.5f * LVAE_LOG2E * p;
+                        v1[e] = LVAE_LOG2E * xs * p;
+                        csum += xs * xs * p + logvar + LVAE_LOG_2PI;
+                        nsum += logvar + LVAE_LOG_2PI;
+                        const float t = 2.0f * fabsf(xs) * sqrtf(p) + 3.0f;
+                        cond += 0.5f * t * t;
+                        if (dparams) {
+                            dparams[(row * 3 + 0) * DC + d] = xv;
+                            dparams[(row * 3 + 1) * DC + d] = sqrtf(0.5f * LVAE_LOG2E * p);
+                            dparams[(row * 3 + 2) * DC + d] = -0.5f * LVAE_LOG2E * (logvar + LVAE_LOG_2PI);
+                        }
+                    } else if (POINT) {
+                        v0[e] = 1.0f;
+                        v1[e] = -2.0f * xs;
+                        csum += xs * xs;
+                    } else {
+                        v0[e] = xs * xs;
+                        v1[e] = xs;
+                    }
+                } else if (GAUSS && dparams && d < DC) {
+                    dparams[(row * 3 + 0) * DC + d] = 0.f;
+                    dparams[(row * 3 + 1) * DC + d] = 0.f;
+                    dparams[(row * 3 + 2) * DC + d] = 0.f;
                 }
-            } else if (GAUSS && dparams && d < DC) {
-                dparams[(row * 3 + 0) * DC + d] = 0.f;
-                dparams[(row * 3 + 1) * DC + d] = 0.f;
-                dparams[(row * 3 + 2) * DC + d] = 0.f;
+            }
+        }
+        if (row < npad && out) {
+            if (FRAG) {
+                f32x4* o = reinterpret_cast<f32x4*>(out + blk * (int64_t)DP * 64 + q * 256);
+                o[r] = v0;
+                o[32 + r] = v1;
+            } else {
+                *reinterpret_cast<f32x4*>(out + row * 2 * DP + 4 * q) = v0;
+                *reinterpret_cast<f32x4*>(out + row * 2 * DP + DP + 4 * q) = v1;
+            }
+        }
+        if (bias || GAUSS) {
+            for (int off = NQ >> 1; off >= 1; off >>= 1) {       // the row's NQ lanes are consecutive
+                csum += __shfl_xor(csum, off, 64);
+                cond += __shfl_xor(cond, off, 64);
+                nsum += __shfl_xor(nsum, off, 64);
+            }
+            if (bias && q == 0 && row < npad) {
+                float bv = GAUSS ? -0.5f * LVAE_LOG2E * csum : (POINT ? csum : 0.f);
+                if (!valid) bv = FRAG ? (POINT ? INFINITY : -INFINITY) : 0.f;
+                bias[row] = bv;
+            }
+            if (GAUSS && valid) {
+                // the density's normaliser bounds every term of the row: v_ij <= -0.5 log2e sum_d log(2 pi var)
+                const float nrm = -0.5f * LVAE_LOG2E * nsum;
+                cond_max = fmaxf(cond_max, cond);
+                norm_max = fmaxf(norm_max, nrm);
+                if (q == 0) norm_acc += nrm;
             }
         }
     }
-    if (row < npad && out) {
-        if (FRAG) {
-            f32x4* o = reinterpret_cast<f32x4*>(out + blk * (int64_t)DP * 64 + q * 256);
-            o[r] = v0;
-            o[32 + r] = v1;
-        } else {
-            *reinterpret_cast<f32x4*>(out + row * 2 * DP + 4 * q) = v0;
-            *reinterpret_cast<f32x4*>(out + row * 2 * DP + DP + 4 * q) = v1;
+    if (GAUSS) {          // header statistics: wave shuffles, then one set of atomics per workgroup
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            cond_max = fmaxf(cond_max, __shfl_xor(cond_max, off, 64));
+            norm_max = fmaxf(norm_max, __shfl_xor(norm_max, off, 64));
+            norm_acc += __shfl_xor(norm_acc, off, 64);
         }
-    }
-    if (bias || GAUSS) {
-        sm_c[r * NQ + q] = csum;
-        sm_k[r * NQ + q] = cond;
-        sm_n[r * NQ + q] = nsum;
+        if ((tid & 63) == 0) {
+            sm_w[tid >> 6][0] = cond_max;
+            sm_w[tid >> 6][1] = norm_max;
+            sm_w[tid >> 6][2] = norm_acc;
+        }
         __syncthreads();
-        if (q == 0 && row < npad) {
-            float c = 0.f, k = 0.f, nn = 0.f;
-            for (int j = 0; j < NQ; ++j) {
-                c += sm_c[r * NQ + j];
-                k += sm_k[r * NQ + j];
-                nn += sm_n[r * NQ + j];
+        if (tid == 0) {
+            const int nw = (blockDim.x + 63) >> 6;
+            for (int w = 1; w < nw; ++w) {
+                cond_max = fmaxf(cond_max, sm_w[w][0]);
+                norm_max = fmaxf(norm_max, sm_w[w][1]);
+                norm_acc += sm_w[w][2];
             }
-            if (bias) {
-                float b = GAUSS ? -0.5f * LVAE_LOG2E * c : (POINT ? c : 0.f);
-                if (!valid) b = FRAG ? (POINT ? INFINITY : -INFINITY) : 0.f;
-                bias[row] = b;
-            }
-            if (GAUSS && !FRAG && valid) {
-                atomicMax(&hdr->cond_bits, __float_as_uint(k));
-                atomicMax(&hdr->cmax_key, lvae_float_key(-0.5f * LVAE_LOG2E * nn));
-            }
-            if (GAUSS && FRAG) {
-                // the density's normaliser bounds every term of row `row`: v_ij <= -0.5 log2e sum_d log(2 pi var).
-                // FRAG: the 32 row threads are lanes 0..31 of wave 0 -> one pair of atomics per block
-                unsigned kb = valid ? __float_as_uint(k) : 0u;
-                unsigned nk = valid ? lvae_float_key(-0.5f * LVAE_LOG2E * nn) : 0u;
-#pragma unroll
-                for (int off = 16; off >= 1; off >>= 1) {
-                    kb = max(kb, (unsigned)__shfl_xor((int)kb, off, 64));
-                    nk = max(nk, (unsigned)__shfl_xor((int)nk, off, 64));
-                }
-                float nsum32 = valid ? -0.5f * LVAE_LOG2E * nn : 0.f;
-#pragma unroll
-                for (int off = 16; off >= 1; off >>= 1) nsum32 += __shfl_xor(nsum32, off, 64);
-                if (r == 0) {
-                    atomicMax(&hdr->cond_bits, kb);
-                    atomicMax(&hdr->cmax_key, nk);
-                    atomicAdd(&hdr->norm_sum, (double)nsum32);
-                }
+            if (norm_max > -INFINITY) {      // at least one valid row
+                atomicMax(&hdr->cond_bits, __float_as_uint(cond_max));
+                atomicMax(&hdr->cmax_key, lvae_float_key(norm_max));
+                if (FRAG) atomicAdd(&hdr->norm_sum, (double)norm_acc);
             }
         }
     }
@@ -302,7 +324,7 @@ int lvae_launch_prep(int src, bool frag, const float* x, const float* spread, in
                      int64_t n, int64_t npad, int D, int DP, PairHeader* hdr, int64_t ngauss,
                      float* out, float* bias, float* dparams, int DC, hipStream_t st) {
     const int threads = 32 * (DP / 4);
-    const dim3 grid((unsigned)lvae_ceil_div(npad, 32));
+    const dim3 grid((unsigned)lvae_ceil_div(npad, 32 * PREP_RB));
     const double inv = 1.0 / (double)ngauss;
 #define LVAE_PREP(S, F)                                                                          \
     hipLaunchKernelGGL((prep_operand_kernel<S, F>), grid, dim3(threads), 0, st, x, spread,        \
