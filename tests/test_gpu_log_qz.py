@@ -218,3 +218,27 @@ def test_partial_logsumexp_blocks_merge_to_the_full_result():
     rest = E.log_qz_partial(dev(mu[275:]), dev(logvar[275:]), dev(z))
     two = E.lse_combine(own, rest, np.log(N_))
     np.testing.assert_allclose(two.cpu().numpy(), ref, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("n_base,reps,D,M_", [(4096, 256, 64, 384),        # N = 1,048,576, D = 64: C3's posterior count
+                                              (4096, 4097, 32, 256)])      # N = 16,781,312 > 2^24: no fixed reference
+def test_large_posterior_counts(n_base, reps, D, M_):
+    """Scale test of the posterior axis (64-bit indexing, split planning, and -- above 2^24 posteriors -- the
+    running-maximum-only path).  The aggregate posterior of a k-fold replicated set equals that of the base
+    set (log q is a mean over posteriors), so the big call is checked against the small one and the small one
+    against the oracle."""
+    from lvae import estimators as E
+    rng = np.random.default_rng(n_base + reps)
+    mu = rng.standard_normal((n_base, D)).astype(np.float32)
+    logvar = (0.5 * rng.standard_normal((n_base, D)) - 1.0).astype(np.float32)
+    z = (mu[:M_] + rng.standard_normal((M_, D)) * np.exp(0.5 * logvar[:M_])).astype(np.float32)
+    ref, _ = onp.approximate_log_q_z(mu, logvar, z, method="all", prod_marginals=False, reduce_mean=False)
+    small, _ = E.approximate_log_q_z(dev(mu), dev(logvar), dev(z), method="all", prod_marginals=False,
+                                     reduce_mean=False)
+    np.testing.assert_allclose(small.cpu().numpy(), ref, rtol=1e-4, atol=1e-3)
+    mu_big, lv_big = dev(mu).repeat(reps, 1), dev(logvar).repeat(reps, 1)
+    assert mu_big.shape[0] == n_base * reps
+    big, _ = E.approximate_log_q_z(mu_big, lv_big, dev(z), method="all", prod_marginals=False, reduce_mean=False)
+    np.testing.assert_allclose(big.cpu().numpy(), small.cpu().numpy(), rtol=0, atol=5e-4)
+    del mu_big, lv_big
+    torch.cuda.empty_cache()
