@@ -7,7 +7,9 @@
  * function it replaces (path:line under NewsVAE/).  INTEGRATION.md shows the binding.
  *
  * Conventions
- *  - every pointer is DEVICE memory, float32, row-major contiguous, owned by the caller;
+ *  - every pointer is DEVICE memory, float32, row-major contiguous, owned by the caller, unless the entry
+ *    point says otherwise (bandwidth lists live on the host; labels are uint8, class indices int64, scalar
+ *    statistics float64);
  *  - the library never allocates user-visible memory: scratch comes in through `ws` / `ws_bytes`
  *    (size from the matching *_workspace_bytes query; 256-byte aligned);
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous on it;
@@ -58,6 +60,11 @@ int lvae_version(void);
  * z [M,D]; mu, spread [N,D]; log_qz [M]; log_qz_prod_marg [M] or NULL.
  * ------------------------------------------------------------------------------------------- */
 int lvae_log_qz_workspace_bytes(int64_t M, int64_t N, int D, int with_prod_marg, int64_t* out_bytes);
+int lvae_log_qz_f32(const float* z, const float* mu, const float* spread, int spread_kind,
+                    int64_t M, int64_t N, int D, float log_norm,
+                    int exclude_diag, int64_t diag_offset, int path,
+                    float* log_qz, float* log_qz_prod_marg,
+                    void* ws, int64_t ws_bytes, void* stream);
 
 /* Backward of lvae_log_qz_f32 (the reference differentiates approximate_log_q_z with autograd inside its
  * training objectives, loss_and_optimisation.py:925-1018 via modules/encoder.py:102-107).
@@ -94,11 +101,6 @@ int lvae_kl_diag_bwd_f32(const float* mu, const float* logvar, int64_t N, int D,
  * the posterior axis, 32-row blocks per split, splits of the direct path, 32-row blocks, workspace bytes}.
  * Host only; used by the tests of the grid quantisation. */
 int lvae_plan_info(int64_t M, int64_t N, int D, int prod_marginals, int64_t* out);
-int lvae_log_qz_f32(const float* z, const float* mu, const float* spread, int spread_kind,
-                    int64_t M, int64_t N, int D, float log_norm,
-                    int exclude_diag, int64_t diag_offset, int path,
-                    float* log_qz, float* log_qz_prod_marg,
-                    void* ws, int64_t ws_bytes, void* stream);
 
 /* Column-sharded variant: the same reduction over the posteriors handed in, returned un-normalised as
  * (row_max, row_sum) with log_qz[i] = row_max[i] + log(row_sum[i]) - log_norm, so that partial results

@@ -441,9 +441,8 @@ int lvae_launch_ksum_columns(const double* partial, int nsplit, int64_t cpad, in
 // b may be absent (finalisation of a single partial).  The rescaled sums are formed in float64: a sum may be
 // as large as N * 2^100 when its reference is the fixed one.
 __global__ void __launch_bounds__(256)
-lse_combine_kernel(const float* __restrict__ max_a, const float* __restrict__ sum_a,
-                   const float* __restrict__ max_b, const float* __restrict__ sum_b, int64_t n, float log_norm,
-                   float* __restrict__ out, float* __restrict__ out_max, float* __restrict__ out_sum) {
+lse_combine_kernel(const float* max_a, const float* sum_a, const float* max_b, const float* sum_b, int64_t n,
+                   float log_norm, float* out, float* out_max, float* out_sum) {      // (outputs may alias inputs)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float ma = max_a[i];
