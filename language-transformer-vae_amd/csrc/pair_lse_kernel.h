@@ -164,7 +164,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
 
     // ---- streaming of the reduced-axis operand through LDS -------------------------------------
     // The four waves of a workgroup sweep the same reduced-axis blocks (each for its own columns), so
-    // they share one three-stage ring in LDS and fill it together with LDS-DMA
+    // they share one ring of PF + 1 stages in LDS (PF = 3 chunks in flight) and fill it together with LDS-DMA
     // (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR staging; each wave brings a quarter
     // of every chunk).  The fragment-major global layout is lane-linear, which is exactly the image an
     // LDS-DMA writes, and the later ds_read_b128 of lane l at offset 16*l is conflict-free.

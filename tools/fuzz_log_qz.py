@@ -1,0 +1,59 @@
+"""Randomised shape sweep of lvae_log_qz_f32 (all paths, with / without prod-marginals and diagonal exclusion)
+and the kernel sums against the NumPy oracle.  A development aid: prints every failing case."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from lvae import _native as N
+from lvae import estimators as E
+from oracle import oracle_np as onp
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+bad = 0
+for c in range(cases):
+    D = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 31, 32, 33, 48, 64, 65, 100, 128, 130]))
+    Nn = int(rng.integers(1, 700))
+    M = int(rng.integers(1, 700))
+    mu = rng.standard_normal((Nn, D)).astype(np.float32) * rng.choice([0.1, 1.0, 3.0])
+    lv = (rng.standard_normal((Nn, D)) * rng.choice([0.1, 0.5, 1.5]) + rng.choice([-3.0, -1.0, 0.0])).astype(np.float32)
+    idx = rng.integers(0, Nn, M)
+    z = (mu[idx] + rng.standard_normal((M, D)) * np.exp(0.5 * lv[idx]) * rng.choice([1.0, 3.0])).astype(np.float32)
+    pm = bool(rng.integers(0, 2))
+    ref, refpm = onp.approximate_log_q_z(mu, lv, z, method="all", prod_marginals=True, reduce_mean=False)
+    for path in (0, 1, 2, 3):
+        if path == 1 and D > 128: continue
+        if path == 3 and D > 64: continue
+        try:
+            lq, lqpm = E.approximate_log_q_z(dev(mu), dev(lv), dev(z), method="all", prod_marginals=pm,
+                                             reduce_mean=False, path=path)
+            got = lq.cpu().numpy()
+            scale = max(1.0, np.abs(ref).max())
+            tol = 1e-4 * scale if path in (0, 2) else 3e-3 * scale     # forced MFMA paths: conditioning is the caller's risk
+            err = np.abs(got - ref).max()
+            ok = np.isfinite(got).all() and err <= tol
+            if pm:
+                errpm = np.abs(lqpm.cpu().numpy() - refpm).max()
+                ok = ok and errpm <= 1e-4 * max(1.0, np.abs(refpm).max())
+            if not ok:
+                bad += 1
+                print(f"FAIL case {c}: N={Nn} M={M} D={D} path={path} pm={pm} err={err:.3e} tol={tol:.1e}", flush=True)
+        except N.LvaeError as e:
+            bad += 1
+            print(f"ERROR case {c}: N={Nn} M={M} D={D} path={path} pm={pm}: {e}", flush=True)
+    # kernel sums (both math modes) on the same points
+    if D <= 128:
+        al = [0.1 * i for i in range(15)] if c % 2 else [0.3]
+        a64, b64 = z.astype(np.float64), mu.astype(np.float64)
+        d2 = 1e-5 + np.abs((a64 ** 2).sum(1)[:, None] + (b64 ** 2).sum(1)[None] - 2 * a64 @ b64.T)
+        want = sum(np.exp(-x * d2) for x in al).sum()
+        for mode in (N.MATH_FP32, N.MATH_BF16X3):
+            with N.pair_math(mode):
+                got = float(E.kernel_sum(dev(z), dev(mu), al, 1e-5, False, 0))
+            # (d2 comes from the fp32 expansion |a|^2 + |b|^2 - 2ab: its rounding, times alpha, is the floor)
+            if not abs(got - want) <= 1e-4 * want + 1e-12:
+                bad += 1
+                print(f"FAIL ksum case {c}: na={M} nb={Nn} D={D} mode={mode} got={got} want={want}", flush=True)
+print(f"{cases} cases, {bad} failures", flush=True)
