@@ -70,8 +70,10 @@ int lvae_log_qz_f32(const float* z, const float* mu, const float* spread, int sp
  * training objectives, loss_and_optimisation.py:925-1018 via modules/encoder.py:102-107).
  * Inputs: the forward inputs (logvar only), log_norm, the forward result log_qz [M] (needed with g_log_qz),
  * and the upstream gradients g_log_qz [M] (on log_qz) and/or g_prod_marg [M] (on log_qz_prod_marg); either
- * may be NULL.  Outputs (each may be NULL): d_z [M,D], d_mu [N,D], d_logvar [N,D].  The softmax weights are
- * recomputed, nothing of size M x N is stored.  D <= 64; sized for training-time batches. */
+ * may be NULL.  Outputs (each may be NULL): d_z [M,D], d_mu [N,D], d_logvar [N,D].  Sized for training-time
+ * batches.  D <= 64: the softmax weights are recomputed in registers, nothing of size M x N is stored.
+ * D > 64: the joint weights are read from an explicit N x M matrix of pair densities held in the workspace
+ * (M * N <= 2^28, LVAE_ERR_UNSUPPORTED beyond). */
 int lvae_log_qz_bwd_workspace_bytes(int64_t M, int64_t N, int D, int prod_marginals, int64_t* out_bytes);
 int lvae_log_qz_bwd_f32(const float* z, const float* mu, const float* logvar, int64_t M, int64_t N, int D,
                         float log_norm, const float* log_qz, const float* g_log_qz, const float* g_prod_marg,

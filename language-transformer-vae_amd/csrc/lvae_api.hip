@@ -97,6 +97,9 @@ int lvae_launch_kl_bwd(const float* mu, const float* logvar, const float* g_kl, 
                        hipStream_t st);
 int lvae_launch_lse_combine(const float* max_a, const float* sum_a, const float* max_b, const float* sum_b,
                             int64_t n, float log_norm, float* out, float* out_max, float* out_sum, hipStream_t st);
+int lvae_launch_grad_wide(const float* z, const float* dparams, const float* P, const float* log_qz, float log_norm,
+                          const float* g, const float* h, const float* lse2, int64_t M, int64_t N, int D, int DC,
+                          float* d_z, float* d_mu, float* d_logvar, hipStream_t st);
 size_t lvae_cat_bounds_workspace(int64_t K);
 int lvae_launch_cat_bounds(const float* probs, const int64_t* samples, int64_t K, int64_t V, double* out, void* ws,
                            hipStream_t st);
@@ -410,8 +413,9 @@ struct GradLayout {
     PairPlan p;
     int nsA, nsB;                 // splits of the looped axis: posteriors (sample sweep), samples (posterior sweep)
     int64_t rowsA, rowsB;
-    size_t off_lse, off_rec, off_pdz, off_pdp, total;
+    size_t off_lse, off_rec, off_pdz, off_pdp, off_pmat, total;
 };
+#define LVAE_GRAD_WIDE_MAX_PAIRS (1LL << 28)     // D > 64: the explicit N x M pair matrix is capped at 1 GiB
 
 static int grad_splits(int64_t kept, int64_t looped, int64_t* rows) {
     const int64_t waves = lvae_ceil_div(kept, 64);
@@ -435,6 +439,8 @@ static GradLayout grad_layout(int64_t M, int64_t N, int D, bool pm) {
     g.off_rec = o; o = lvae_align256(o + (size_t)M * (2 * DC + 4) * sizeof(float));
     g.off_pdz = o; o = lvae_align256(o + (size_t)g.nsA * M * DC * sizeof(float));
     g.off_pdp = o; o = lvae_align256(o + (size_t)g.nsB * N * 2 * DC * sizeof(float));
+    g.off_pmat = o;
+    if (D > 64 && M * N <= LVAE_GRAD_WIDE_MAX_PAIRS) o = lvae_align256(o + (size_t)M * N * sizeof(float));
     g.total = o;
     return g;
 }
@@ -453,8 +459,11 @@ extern "C" int lvae_log_qz_bwd_f32(const float* z, const float* mu, const float*
                                    void* ws, int64_t ws_bytes, void* stream) {
     int rc = check_pair_shapes(z, mu, logvar, LVAE_SPREAD_LOGVAR, M, N, D);
     if (rc) return rc;
-    LVAE_CHECK_ARG(D <= 64, "the backward pass needs D <= 64 (got D=%d)", D);
     LVAE_CHECK_ARG(g_log_qz || g_prod_marg, "at least one upstream gradient is required");
+    if (D > 64 && (M * N > LVAE_GRAD_WIDE_MAX_PAIRS || M >= (1LL << 31) || N >= (1LL << 31)))
+        return lvae_set_error(LVAE_ERR_UNSUPPORTED,
+                              "the backward pass for D > 64 keeps an explicit N x M pair matrix and is sized for "
+                              "training batches: M * N <= 2^28 (got M=%lld, N=%lld)", (long long)M, (long long)N);
     LVAE_CHECK_ARG(!g_log_qz || log_qz, "log_qz (the forward result) is required with g_log_qz");
     LVAE_CHECK_ARG(d_z || d_mu || d_logvar, "at least one output gradient is required");
     const bool pm = g_prod_marg != nullptr;
@@ -482,6 +491,15 @@ extern "C" int lvae_log_qz_bwd_f32(const float* z, const float* mu, const float*
     }
     const float* gq = g_log_qz;
     const float* lq = g_log_qz ? log_qz : nullptr;
+    if (D > 64) {
+        float* pmat = (float*)(base + g.off_pmat);
+        if (gq) {
+            rc = lvae_launch_pair_matrix(mu, logvar, LVAE_SPREAD_LOGVAR, z, N, M, D, 0, nullptr, pmat, st);
+            if (rc) return rc;
+        }
+        return lvae_launch_grad_wide(z, dparams, pmat, lq, log_norm, gq, g_prod_marg, lse2, M, N, D, p.DC, d_z, d_mu,
+                                     d_logvar, st);
+    }
     if (d_z) {
         rc = lvae_launch_grad_sample(z, dparams, lq, log_norm, gq, g_prod_marg, lse2, M, N, D, p.DC, g.nsA,
                                      g.rowsA, pdz, st);

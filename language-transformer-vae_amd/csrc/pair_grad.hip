@@ -15,7 +15,9 @@
 // size M x N is stored.  Everything is in the base-2 domain of the direct parameters
 // (w = sqrt(0.5 log2e / var), b = -0.5 log2e (logvar + log 2pi), y = (z - mu) w, t2 = b - y^2):
 //     (z - mu)/var = 2 y w / log2e,   (z - mu)^2/var = 2 y^2 / log2e.
-// Sized for training-time batches (the reference trains at B = 32) up to a few thousand rows; D <= 64.
+// Sized for training-time batches (the reference trains at B = 32) up to a few thousand rows.  D <= 64 takes
+// the register-resident sweeps below; wider latents take grad_wide_* (one thread per (kept element, dimension),
+// the joint weights read from an explicit N x M matrix of pair log-densities -- training batches only).
 #include "pair_plan.h"
 
 #define GRAD_REC_EXTRA 4      // L2_i, g_i, h_i, pad  (sample record = [z (DC) | lse2 (DC) | these])
@@ -157,6 +159,76 @@ pair_grad_posterior_kernel(const float* __restrict__ dparams, const float* __res
             o[DC + d] = dlv[d];
         }
     }
+}
+
+// ---- D > 64: one thread per (kept element, dimension) ----------------------------------------------------
+// The joint weight p_ij needs the density over ALL dimensions, which a (sample, dimension) thread does not see:
+// it is read from P [N][M], the explicit matrix of natural-log pair densities (pair_matrix_kernel, the layout of
+// lvae_log_prob_pairs_f32).  The prod-marginals weight r_ijd is local to the dimension.  No partials, no atomics.
+__global__ void __launch_bounds__(256)
+grad_wide_sample_kernel(const float* __restrict__ z, const float* __restrict__ dparams, const float* __restrict__ P,
+                        const float* __restrict__ log_qz, float log_norm, const float* __restrict__ g,
+                        const float* __restrict__ h, const float* __restrict__ lse2, int64_t M, int64_t N, int D,
+                        int DC, float* __restrict__ d_z) {
+    const int d = blockIdx.y * 256 + threadIdx.x;
+    const int64_t i = blockIdx.x;
+    if (d >= D) return;
+    const float zi = z[i * D + d];
+    const float L = log_qz ? log_qz[i] + log_norm : 0.f;
+    const float gi = g ? g[i] : 0.f;
+    const float hi = h ? h[i] : 0.f;
+    const float ls = h ? lse2[i * DC + d] : 0.f;
+    float acc = 0.f;
+    for (int64_t j = 0; j < N; ++j) {
+        const float m = dparams[(j * 3 + 0) * DC + d];
+        const float w = dparams[(j * 3 + 1) * DC + d];
+        const float b = dparams[(j * 3 + 2) * DC + d];
+        const float y = (zi - m) * w;
+        float G = 0.f;
+        if (g) G = gi * __expf(P[j * M + i] - L);
+        if (h) G = fmaf(hi, lvae_exp2(fmaf(-y, y, b) - ls), G);
+        acc = fmaf(-(G * w), y, acc);
+    }
+    d_z[i * D + d] = acc * (2.0f / LVAE_LOG2E);
+}
+
+__global__ void __launch_bounds__(256)
+grad_wide_posterior_kernel(const float* __restrict__ z, const float* __restrict__ dparams,
+                           const float* __restrict__ P, const float* __restrict__ log_qz, float log_norm,
+                           const float* __restrict__ g, const float* __restrict__ h,
+                           const float* __restrict__ lse2, int64_t M, int64_t N, int D, int DC,
+                           float* __restrict__ d_mu, float* __restrict__ d_logvar) {
+    const int d = blockIdx.y * 256 + threadIdx.x;
+    const int64_t j = blockIdx.x;
+    if (d >= D) return;
+    const float m = dparams[(j * 3 + 0) * DC + d];
+    const float w = dparams[(j * 3 + 1) * DC + d];
+    const float b = dparams[(j * 3 + 2) * DC + d];
+    float dmu = 0.f, dlv = 0.f;
+    for (int64_t i = 0; i < M; ++i) {
+        const float y = (z[i * D + d] - m) * w;
+        float G = 0.f;
+        if (g) G = g[i] * __expf(P[j * M + i] - (log_qz[i] + log_norm));
+        if (h) G = fmaf(h[i], lvae_exp2(fmaf(-y, y, b) - lse2[i * DC + d]), G);
+        dmu = fmaf(G * w, y, dmu);
+        dlv = fmaf(G, fmaf(y * (1.0f / LVAE_LOG2E), y, -0.5f), dlv);
+    }
+    if (d_mu) d_mu[j * D + d] = dmu * (2.0f / LVAE_LOG2E);
+    if (d_logvar) d_logvar[j * D + d] = dlv;
+}
+
+int lvae_launch_grad_wide(const float* z, const float* dparams, const float* P, const float* log_qz, float log_norm,
+                          const float* g, const float* h, const float* lse2, int64_t M, int64_t N, int D, int DC,
+                          float* d_z, float* d_mu, float* d_logvar, hipStream_t st) {
+    const unsigned dy = (unsigned)lvae_ceil_div(D, 256);
+    if (d_z)
+        hipLaunchKernelGGL(grad_wide_sample_kernel, dim3((unsigned)M, dy), dim3(256), 0, st, z, dparams, P, log_qz,
+                           log_norm, g, h, lse2, M, N, D, DC, d_z);
+    if (d_mu || d_logvar)
+        hipLaunchKernelGGL(grad_wide_posterior_kernel, dim3((unsigned)N, dy), dim3(256), 0, st, z, dparams, P, log_qz,
+                           log_norm, g, h, lse2, M, N, D, DC, d_mu, d_logvar);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
 }
 
 // out[row][d] = sum_k partial[k][row][off + d]   (d < D; partial rows are `stride` floats wide)

@@ -130,7 +130,7 @@ def approximate_log_q_z(mu, logvar, latent_z, method="chen", dataset_size=42068,
     log_norm = math.log(x_batch * dataset_size) if method == "chen" else math.log(x_batch)   # :207,:215
     if _needs_grad(mu, logvar, latent_z):
         # training-time use (the objectives of :925-1018 differentiate this estimator): HIP forward and
-        # HIP backward behind torch.autograd; D <= 64
+        # HIP backward behind torch.autograd (D > 64: training batches only, M * N <= 2^28)
         log_q_z, log_q_z_prod_marg = _LogQz.apply(mu, logvar, latent_z, log_norm, prod_marginals, path)
         if not prod_marginals:
             log_q_z_prod_marg = None

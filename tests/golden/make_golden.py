@@ -376,6 +376,10 @@ def main():
         return
     torch.set_num_threads(8)
     lo, kde, enc, mi = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-wide-grad":
+        case_grad(lo, "d100", 28, 40, 56, 100)
+        case_grad(lo, "d128", 29, 32, 32, 128)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--only-generative-mi":
         case_mi_generative(mi, "k64_v500", 26, 64, 500, False)
         case_mi_generative(mi, "k128_v600_peaked", 27, 128, 600, True)
@@ -408,6 +412,8 @@ def main():
     case_grad_encode_tail(lo, 25, 32, 3, 32)
     case_mi_generative(mi, "k64_v500", 26, 64, 500, False)
     case_mi_generative(mi, "k128_v600_peaked", 27, 128, 600, True)
+    case_grad(lo, "d100", 28, 40, 56, 100)
+    case_grad(lo, "d128", 29, 32, 32, 128)
 
 
 if __name__ == "__main__":
