@@ -217,6 +217,8 @@ int lvae_kde_score_f32(const float* X, const float* Y, int64_t n, int64_t m, int
  * unbiased == 0: maximum_mean_discrepancy (loss_and_optimisation.py:46-60) with alphas = {1/D^2},
  *   dist_eps = 0: mean(Kxx) + mean(Kyy) - 2 mean(Kxy), diagonals included.
  * x [n1,D], y [n2,D] device; alphas: HOST array of n_alpha >= 1 non-negative floats (n_alpha <= 32).
+ * D <= 128: distances on the matrix cores; 128 < D <= 4096 (wide latents at training-time batch sizes):
+ * direct differences on the vector ALU, O(n1 n2 D).
  * out: 4 float64 in device memory = {statistic, sum Kxx, sum Kyy, sum Kxy}. */
 int lvae_mmd_workspace_bytes(int64_t n1, int64_t n2, int D, int64_t* out_bytes);
 int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int64_t n2, int D, const float* alphas,

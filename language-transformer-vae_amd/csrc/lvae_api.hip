@@ -100,6 +100,9 @@ int lvae_launch_lse_combine(const float* max_a, const float* sum_a, const float*
 int lvae_launch_grad_wide(const float* z, const float* dparams, const float* P, const float* log_qz, float log_norm,
                           const float* g, const float* h, const float* lse2, int64_t M, int64_t N, int D, int DC,
                           float* d_z, float* d_mu, float* d_logvar, hipStream_t st);
+int lvae_launch_ksum_wide(const float* a, const float* b, int64_t na, int64_t nb, int D, const PairHeader* hdr,
+                          bool excl, int64_t excl_offset, int nsplit, int64_t cpad, double* partial,
+                          hipStream_t st);
 size_t lvae_cat_bounds_workspace(int64_t K);
 int lvae_launch_cat_bounds(const float* probs, const int64_t* samples, int64_t K, int64_t V, double* out, void* ws,
                            hipStream_t st);
@@ -863,11 +866,16 @@ static int ksum_pass(const float* a, int64_t na, const float* b, int64_t nb, int
     float* rbias = (float*)(base + p.off_rbias);
     float* cop = (float*)(base + p.off_cop);
     float2* partial = (float2*)(base + p.off_partial);
-    const bool bx = ksum_use_bx(p);
-    int rc = prep_ksum_operands(p, bx, a, na, b, nb, D, hdr, rfrag, rbias, cop, st);
-    if (rc) return rc;
-    rc = (bx ? lvae_launch_pair_bf16x3 : lvae_launch_pair_mfma)(p, rfrag, rbias, cop, partial, hdr, -1.f, 0, excl, 0,
-                                                                epi, nullptr, a == b ? 1 : 0, st);
+    int rc;
+    if (p.DP == 0) {      // D > 128: direct differences on the vector ALU (no symmetric walk)
+        rc = lvae_launch_ksum_wide(a, b, na, nb, D, hdr, excl, 0, p.nsplit, p.cpad, (double*)partial, st);
+    } else {
+        const bool bx = ksum_use_bx(p);
+        rc = prep_ksum_operands(p, bx, a, na, b, nb, D, hdr, rfrag, rbias, cop, st);
+        if (rc) return rc;
+        rc = (bx ? lvae_launch_pair_bf16x3 : lvae_launch_pair_mfma)(p, rfrag, rbias, cop, partial, hdr, -1.f, 0, excl,
+                                                                    0, epi, nullptr, a == b ? 1 : 0, st);
+    }
     if (rc) return rc;
     return lvae_launch_finalize_ksum((const double*)partial, p.nsplit, p.cpad, na, out, st);
 }
@@ -877,7 +885,7 @@ extern "C" int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int6
                                 void* ws, int64_t ws_bytes, void* stream) {
     LVAE_CHECK_ARG(x && y && out, "x, y and out must be non-NULL");
     LVAE_CHECK_ARG(n1 >= 2 && n2 >= 2, "need n1, n2 >= 2");
-    LVAE_CHECK_ARG(D >= 1 && D <= 128, "the MMD path needs 1 <= D <= 128 (got %d)", D);
+    LVAE_CHECK_ARG(D >= 1 && D <= 4096, "the MMD path needs 1 <= D <= 4096 (got %d)", D);
     LVAE_CHECK_ARG(n1 < (1LL << 31) && n2 < (1LL << 31), "n1, n2 must be below 2^31");
     KsumParams kp;
     int zeros = 0;
@@ -923,7 +931,7 @@ extern "C" int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, i
     LVAE_CHECK_ARG(a && b, "a and b must be non-NULL");
     LVAE_CHECK_ARG(out_total || out_colsum, "at least one of out_total / out_colsum is required");
     LVAE_CHECK_ARG(na >= 1 && nb >= 1, "need na, nb >= 1");
-    LVAE_CHECK_ARG(D >= 1 && D <= 128, "the kernel-sum path needs 1 <= D <= 128 (got %d)", D);
+    LVAE_CHECK_ARG(D >= 1 && D <= 4096, "the kernel-sum path needs 1 <= D <= 4096 (got %d)", D);
     LVAE_CHECK_ARG(na < (1LL << 31) && nb < (1LL << 31), "na, nb must be below 2^31");
     LVAE_CHECK_ARG(!symmetric || (diag_offset >= 0 && diag_offset % 32 == 0 && diag_offset + na <= nb && !out_colsum),
                    "symmetric evaluation: a must be rows diag_offset.. of b, diag_offset %% 32 == 0, totals only");
@@ -945,14 +953,21 @@ extern "C" int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, i
     if (kp.n == 0 && kp.c[0] == 0.f) {      // only alpha = 0 bandwidths: no pair kernel needed
         LVAE_HIP(hipMemsetAsync(partial, 0, (size_t)p.nsplit * p.cpad * sizeof(double), st));
     } else {
-        const bool bx = ksum_use_bx(p);
-        rc = prep_ksum_operands(p, bx, a, na, b, nb, D, hdr, (float*)(base + p.off_rfrag),
-                                (float*)(base + p.off_rbias), (float*)(base + p.off_cop), st);
-        if (rc) return rc;
-        rc = (bx ? lvae_launch_pair_bf16x3 : lvae_launch_pair_mfma)(
-            p, (float*)(base + p.off_rfrag), (float*)(base + p.off_rbias), (float*)(base + p.off_cop), partial, hdr,
-            -1.f, 0, exclude_diag != 0, diag_offset, ksum_epi(kp), nullptr, sym, st);
-        if (rc) return rc;
+        if (p.DP == 0) {  // D > 128: direct differences on the vector ALU; every pair of the owned rows is evaluated
+                          // (a symmetric request is served as a plain one: the owners' totals still add up)
+            rc = lvae_launch_ksum_wide(a, b, na, nb, D, hdr, exclude_diag != 0, diag_offset, p.nsplit, p.cpad,
+                                       (double*)partial, st);
+            if (rc) return rc;
+        } else {
+            const bool bx = ksum_use_bx(p);
+            rc = prep_ksum_operands(p, bx, a, na, b, nb, D, hdr, (float*)(base + p.off_rfrag),
+                                    (float*)(base + p.off_rbias), (float*)(base + p.off_cop), st);
+            if (rc) return rc;
+            rc = (bx ? lvae_launch_pair_bf16x3 : lvae_launch_pair_mfma)(
+                p, (float*)(base + p.off_rfrag), (float*)(base + p.off_rbias), (float*)(base + p.off_cop), partial,
+                hdr, -1.f, 0, exclude_diag != 0, diag_offset, ksum_epi(kp), nullptr, sym, st);
+            if (rc) return rc;
+        }
     }
     return lvae_launch_ksum_columns((const double*)partial, p.nsplit, p.cpad, na, nb, exclude_diag != 0,
                                     diag_offset, zeros, out_colsum, out_total, st);

@@ -440,3 +440,88 @@ int lvae_launch_perm_lr(const double* partial, const double* diag_partial, int n
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }
+
+// ---- kernel-matrix sums for D > 128 (no MFMA variant: the pair kernel keeps a whole operand row in VGPRs) ---
+// Direct differences, 32 x 32 tiles of pairs staged through LDS 32 dimensions at a time; a workgroup owns 32
+// kept rows and a contiguous share of the reduced-axis tiles, and writes one float64 partial per kept row
+// into the same [nsplit][cpad] layout the MFMA kernel-sum epilogues use (ksum_columns_kernel merges them).
+// Sized for training-time batches with wide latents (the MMD of the reference's encode tail); O(na nb D) on
+// the vector ALU.
+__device__ __forceinline__ float ksum_eval(const KsumParams& kp, float d2) {
+    const float v = fabsf(d2) + kp.eps;
+    if (kp.poly) {
+        const float t = lvae_exp2(v * kp.nbase);
+        float acc = kp.c[kp.n];
+        for (int k = kp.n - 1; k >= 0; --k) acc = fmaf(acc, t, kp.c[k]);
+        return acc;
+    }
+    float f = 0.f;
+    for (int k = 0; k < kp.n; ++k) f += lvae_exp2(v * kp.c[k]);
+    return f;
+}
+
+__global__ void __launch_bounds__(256)
+ksum_wide_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t na, int64_t nb, int D,
+                 const PairHeader* __restrict__ hdr, int excl, int64_t excl_offset, int64_t tiles_per_split,
+                 double* __restrict__ partial, int64_t cpad) {
+    __shared__ float sa[32][33], sb[32][33];
+    __shared__ KsumParams kp;
+    if (threadIdx.x == 0) kp = hdr->ksum;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t i0 = (int64_t)blockIdx.x * 32;
+    const int64_t nbt = (nb + 31) / 32;
+    const int64_t t0 = (int64_t)blockIdx.y * tiles_per_split;
+    int64_t t1 = t0 + tiles_per_split;
+    if (t1 > nbt) t1 = nbt;
+    double rowacc[4] = {0.0, 0.0, 0.0, 0.0};
+    __syncthreads();
+    for (int64_t bt = t0; bt < t1; ++bt) {
+        const int64_t j0 = bt * 32;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int d0 = 0; d0 < D; d0 += 32) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = ty * 4 + r;
+                const bool din = d0 + tx < D;
+                sa[row][tx] = (din && i0 + row < na) ? a[(i0 + row) * D + d0 + tx] : 0.f;
+                sb[row][tx] = (din && j0 + row < nb) ? b[(j0 + row) * D + d0 + tx] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll 8
+            for (int dd = 0; dd < 32; ++dd) {
+                const float bv = sb[tx][dd];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float df = sa[ty * 4 + r][dd] - bv;
+                    acc[r] = fmaf(df, df, acc[r]);
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t i = i0 + ty * 4 + r, j = j0 + tx;
+            if (i < na && j < nb && !(excl && j == i + excl_offset)) rowacc[r] += (double)ksum_eval(kp, acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double v = rowacc[r];
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);     // the 32 lanes that share ty
+        const int64_t i = i0 + ty * 4 + r;
+        if (tx == 0 && i < cpad) partial[(int64_t)blockIdx.y * cpad + i] = v;
+    }
+}
+
+int lvae_launch_ksum_wide(const float* a, const float* b, int64_t na, int64_t nb, int D, const PairHeader* hdr,
+                          bool excl, int64_t excl_offset, int nsplit, int64_t cpad, double* partial,
+                          hipStream_t st) {
+    const int64_t nbt = lvae_ceil_div(nb, 32);
+    const int64_t tps = lvae_ceil_div(nbt, nsplit);
+    const dim3 grid((unsigned)lvae_ceil_div(cpad, 32), (unsigned)nsplit);
+    hipLaunchKernelGGL(ksum_wide_kernel, grid, dim3(256), 0, st, a, b, na, nb, D, hdr, excl ? 1 : 0, excl_offset, tps,
+                       partial, cpad);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}

@@ -63,8 +63,8 @@ def test_argument_validation_and_error_text():
     arr = (ctypes.c_float * 2)(0.1, -1.0)
     rc = lib.lvae_mmd_rbf_f32(dummy, dummy, 8, 8, 32, arr, 2, 1e-5, 1, dummy, dummy, 1 << 30, None)
     assert rc == -1 and b"non-negative" in lib.lvae_last_error()
-    rc = lib.lvae_mmd_rbf_f32(dummy, dummy, 8, 8, 300, arr, 1, 1e-5, 1, dummy, dummy, 1 << 30, None)
-    assert rc == -1 and b"D <= 128" in lib.lvae_last_error()
+    rc = lib.lvae_mmd_rbf_f32(dummy, dummy, 8, 8, 5000, arr, 1, 1e-5, 1, dummy, dummy, 1 << 30, None)
+    assert rc == -1 and b"D <= 4096" in lib.lvae_last_error()
     # workspace checks: missing / misaligned / too small
     rc = lib.lvae_log_qz_f32(dummy, dummy, dummy, 0, 8, 8, 32, 0.0, 0, 0, 0, dummy, None, None, 0, None)
     assert rc == -2 and b"NULL" in lib.lvae_last_error()

@@ -338,3 +338,39 @@ def test_mmd_full_size_properties():
     assert abs(s_xy) <= 6.0 * st.std() + abs(st.mean())
     out2 = E.mmd_permutation_test(x, y + 0.02, alphas, labels=labels)
     assert float(out2["pval"]) == 0.0 and float(out2["statistic"]) > st.max()
+
+
+@pytest.mark.parametrize("n1,n2,D", [(64, 64, 768), (150, 97, 200), (700, 333, 129)])
+def test_mmd_wide_latents(n1, n2, D):
+    """D > 128 (e.g. a 768-dimensional latent): the kernel sums take the direct-difference kernel; statistic,
+    biased MMD, row-block sums with an excluded diagonal and column sums against float64 NumPy."""
+    from lvae import estimators as E
+    from lvae.two_sample import MMDStatistic
+    rng = np.random.default_rng(n1 + D)
+    a = (rng.standard_normal((n1, D)) / np.sqrt(D) * 4).astype(np.float32)
+    b = (rng.standard_normal((n2, D)) / np.sqrt(D) * 4 + 0.02).astype(np.float32)
+    alphas = [0.1 * i for i in range(15)]
+    ref = onp.mmd_statistic_tts(a, b, alphas)
+    got = float(MMDStatistic(n1, n2)(dev(a), dev(b), alphas))
+    assert abs(got - ref) <= 2e-6 * 15
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    for al, eps in (([1.0 / D], 0.0), ([0.0, 0.07, 0.19], 1e-5)):
+        d2 = eps + ((a64[:, None, :] - b64[None]) ** 2).sum(2)
+        K = sum(np.exp(-x * d2) for x in al)
+        tot, cs = E.kernel_sum(dev(a), dev(b), al, eps, False, 0, colsum=True)
+        assert abs(float(tot) - K.sum()) <= 2e-6 * K.sum()
+        np.testing.assert_allclose(cs.cpu().numpy(), K.sum(1), rtol=1e-5)
+    # excluded diagonal at an offset + a symmetric request (served as a plain one for wide latents)
+    d2 = 1e-5 + ((b64[:, None, :] - b64[None]) ** 2).sum(2)
+    K = sum(np.exp(-x * d2) for x in alphas)
+    lo, hi = 32, min(n2, 96)
+    want = K[lo:hi].sum() - np.trace(K[lo:hi, lo:hi])
+    for sym in (False, True):
+        got = float(E.kernel_sum(dev(b[lo:hi]), dev(b), alphas, 1e-5, True, lo, symmetric=sym))
+        assert abs(got - want) <= 2e-6 * want, sym
+    # the biased MMD of the encode tail (maximum_mean_discrepancy, loss_and_optimisation.py:46-60)
+    z = dev(a)
+    x = torch.randn(n1, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    got = float(E.maximum_mean_discrepancy(z, prior_sample=x))
+    want = onp.maximum_mean_discrepancy(a, x.cpu().numpy())
+    assert abs(got - want) <= 1e-4 * abs(want) + 1e-7
