@@ -47,6 +47,18 @@ def q_z_estimate(z, mu, var, device=None):
     M, D = z.shape
     Nn = mu.shape[0]
     dev = z.device
+    if D > 128:
+        # wider than the fused kernel's operand registers: the explicit [N, M] matrix (lvae_log_prob_pairs_f32)
+        # reduced row by row with the IW logsumexp kernel (LSE_k - log K); moderate sizes only
+        if M * Nn > (1 << 28):
+            raise N.LvaeError(f"q_z_estimate with D > 128 materialises the [N, M] matrix: N * M <= 2^28 (got {Nn} x {M})")
+        P = _spread_pairs(z, mu, var, N.SPREAD_VAR)
+        with torch.cuda.device(dev):
+            zeros = torch.zeros_like(P)
+            out = torch.empty(Nn, dtype=torch.float32, device=dev)
+            N.check(N.lib().lvae_iw_lse_f32(N.ptr(P), N.ptr(zeros), N.ptr(zeros), Nn, M, N.ptr(out),
+                                            N.stream_ptr(dev)))
+        return (out + (math.log(M) - math.log(Nn))).unsqueeze(0)
     with torch.cuda.device(dev):
         nbytes = N._i64(0)
         N.check(N.lib().lvae_log_qz_workspace_bytes(Nn, M, D, 0, nbytes))    # roles swapped

@@ -91,6 +91,20 @@ def test_q_z_estimate_gll_calc_mi():
         assert abs(mkl - float(g[f"cme_marg_kl_{m}"])) <= 1e-4 * abs(float(g[f"cme_marg_kl_{m}"]))
 
 
+def test_q_z_estimate_wide_latents():
+    """D > 128: explicit matrix + row logsumexp (quirk Q2 kept: one value per POSTERIOR)."""
+    from lvae import mutual_information as MI
+    rng = np.random.default_rng(8)
+    S, N_, D = 90, 130, 200
+    mu = rng.standard_normal((N_, D)).astype(np.float32)
+    var = np.exp(0.4 * rng.standard_normal((N_, D)) - 1).astype(np.float32)
+    z = (mu[rng.integers(0, N_, S)] + rng.standard_normal((S, D)) * 0.6).astype(np.float32)
+    q = MI.q_z_estimate(dev(z), dev(mu), dev(var))
+    want = onp.q_z_estimate(z, mu, var)
+    assert tuple(q.shape) == (1, N_)
+    close(q, np.asarray(want).reshape(1, N_), rtol=1e-4, atol=2e-3)
+
+
 def _kde_stable64(X, Y, bw):
     """float64, max-stabilised evaluation of the KDE score (finite for any query)."""
     X, Y = np.asarray(X, np.float64), np.asarray(Y, np.float64)
