@@ -31,15 +31,15 @@ __device__ __forceinline__ void lse_push(float& m, float& s, float w) {
 // keeps U consecutive rows in flight (U independent 16-B loads per lane); after the shuffle reduction
 // lane u of the group owns row u's densities, so the [B,K] outputs and log_p_x_z move as runs of
 // consecutive floats (U per group, 64*U/G per wave-instruction) instead of one float per group.
-template <bool FROM_EPS, int U>
-__global__ void __launch_bounds__(256)
+template <bool FROM_EPS, int U, int TPB>
+__global__ void __launch_bounds__(TPB)
 sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
                  const float* __restrict__ src, const float* __restrict__ log_p_x_z, int64_t K, int D,
                  int G, float* __restrict__ z_out, float* __restrict__ log_q_z_x,
                  float* __restrict__ log_p_z, float* __restrict__ iw_ll) {
     const int64_t b = blockIdx.x;
     const int gl = threadIdx.x % G;          // lane inside the row group: owns dims 4*gl .. 4*gl+3
-    const int rows_per_iter = (256 / G) * U;
+    const int rows_per_iter = (TPB / G) * U;
     const bool have_post = mu != nullptr;
     f32x4 m4 = {0.f, 0.f, 0.f, 0.f}, lv4 = m4, sd4 = m4, iv4 = m4;
     if (have_post) {
@@ -103,19 +103,22 @@ sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
         }
     }
     if (iw_ll) {
-        __shared__ float sm_m[256], sm_s[256];
+        __shared__ float sm_m[TPB], sm_s[TPB];
         sm_m[threadIdx.x] = lm;
         sm_s[threadIdx.x] = ls;
         __syncthreads();
         if (threadIdx.x < 64) {
-            float mx = fmaxf(fmaxf(sm_m[threadIdx.x], sm_m[threadIdx.x + 64]),
-                             fmaxf(sm_m[threadIdx.x + 128], sm_m[threadIdx.x + 192]));
+            float mx = sm_m[threadIdx.x];
+#pragma unroll
+            for (int t = 1; t < TPB / 64; ++t) mx = fmaxf(mx, sm_m[threadIdx.x + 64 * t]);
             mx = wave_max(mx);
+            // (float exponentials: every factor is <= 1 and the per-lane sums are float already; only the
+            //  accumulation across the workgroup runs in float64)
             double sacc = 0.0;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < TPB / 64; ++t) {
                 const float sv = sm_s[threadIdx.x + 64 * t];
-                if (sv > 0.f) sacc += (double)sv * exp((double)sm_m[threadIdx.x + 64 * t] - (double)mx);
+                if (sv > 0.f) sacc += (double)(sv * __expf(sm_m[threadIdx.x + 64 * t] - mx));
             }
             sacc = wave_sum_d(sacc);
             if (threadIdx.x == 0) iw_ll[b] = (float)((double)mx + log(sacc) - log((double)K));
@@ -265,9 +268,23 @@ int lvae_launch_sample_iw(bool from_eps, const float* mu, const float* logvar, c
         return LVAE_OK;
     }
     if (vec_ok(D, &G)) {
+        // rows per pass of a workgroup = (threads / G) * U: narrower workgroups when a sentence has few samples
+        // (K = 100 at 256 threads leaves 61 % of the lanes idle: 0.35 -> 0.21 ms at B = 65,536); wider ones than
+        // 256 only lose (measured at C5: 0.46 / 0.52 / 0.63 ms at 256 / 512 / 1024 threads)
+        const int umax = G < 8 ? G : 8;
+        const int tpb = K <= (64 / G) * umax ? 64 : (K <= (128 / G) * umax ? 128 : 256);
 #define LVAE_SIW(E, UU)                                                                             \
-    hipLaunchKernelGGL((sample_iw_kernel<E, UU>), grid, dim3(256), 0, st, mu, logvar, src, log_p_x_z, K, D, \
-                       G, z_out, log_q_z_x, log_p_z, iw_ll)
+    do {                                                                                            \
+        if (tpb == 64)                                                                              \
+            hipLaunchKernelGGL((sample_iw_kernel<E, UU, 64>), grid, dim3(64), 0, st, mu, logvar, src, log_p_x_z, K, \
+                               D, G, z_out, log_q_z_x, log_p_z, iw_ll);                             \
+        else if (tpb == 128)                                                                        \
+            hipLaunchKernelGGL((sample_iw_kernel<E, UU, 128>), grid, dim3(128), 0, st, mu, logvar, src, log_p_x_z, K, \
+                               D, G, z_out, log_q_z_x, log_p_z, iw_ll);                             \
+        else                                                                                        \
+            hipLaunchKernelGGL((sample_iw_kernel<E, UU, 256>), grid, dim3(256), 0, st, mu, logvar, src, log_p_x_z, K, \
+                               D, G, z_out, log_q_z_x, log_p_z, iw_ll);                             \
+    } while (0)
         const int U = G < 8 ? G : 8;
         if (from_eps) {
             if (U == 8) LVAE_SIW(true, 8); else if (U == 4) LVAE_SIW(true, 4);

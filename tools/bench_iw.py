@@ -1,0 +1,25 @@
+"""IW reduction (C5: B = 16,384 sentences x K = 1,000 samples, D = 32) timing."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from lvae import estimators as E
+
+def timed(fn, reps=15):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+    return float(np.median(ts)) * 1e-3
+
+g = torch.Generator(device="cuda").manual_seed(0)
+for B, K, D in ((16384, 1000, 32), (16384, 600, 32), (4096, 1000, 64), (65536, 100, 32)):
+    mu = torch.randn(B, D, device="cuda", generator=g); lv = 0.5 * torch.randn(B, D, device="cuda", generator=g) - 1
+    eps = torch.randn(B, K, D, device="cuda", generator=g); lpxz = 5 * torch.randn(B, K, device="cuda", generator=g) - 100
+    t = timed(lambda: E.reparam_iw(mu, lv, eps, lpxz, return_z=False))
+    by = B * K * (4 * D + 4)
+    t2 = timed(lambda: E.reparam_iw(mu, lv, eps, lpxz, return_z=True))
+    by2 = B * K * (8 * D + 4 + 8)
+    print(f"B={B} K={K} D={D}: no-z {t*1e3:.3f} ms {by/t/1e9:.0f} GB/s ({by/t/8e12*100:.1f}%)   +z {t2*1e3:.3f} ms {by2/t2/1e9:.0f} GB/s ({by2/t2/8e12*100:.1f}%)", flush=True)
+    del eps, lpxz
