@@ -217,8 +217,9 @@ int lvae_kde_score_f32(const float* X, const float* Y, int64_t n, int64_t m, int
  * unbiased == 0: maximum_mean_discrepancy (loss_and_optimisation.py:46-60) with alphas = {1/D^2},
  *   dist_eps = 0: mean(Kxx) + mean(Kyy) - 2 mean(Kxy), diagonals included.
  * x [n1,D], y [n2,D] device; alphas: HOST array of n_alpha >= 1 non-negative floats (n_alpha <= 32).
- * D <= 128: distances on the matrix cores; 128 < D <= 4096 (wide latents at training-time batch sizes):
- * direct differences on the vector ALU, O(n1 n2 D).
+ * D <= 256: the cross term -2 x.y on the matrix cores (two dimensions per MFMA step, the squared norms enter
+ * as biases); 256 < D <= 4096 (wide latents at training-time batch sizes): direct differences on the vector
+ * ALU, O(n1 n2 D).
  * out: 4 float64 in device memory = {statistic, sum Kxx, sum Kyy, sum Kxy}. */
 int lvae_mmd_workspace_bytes(int64_t n1, int64_t n2, int D, int64_t* out_bytes);
 int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int64_t n2, int D, const float* alphas,
@@ -291,7 +292,7 @@ int lvae_ks_2samp_f32(const float* a, int64_t n1, const float* b, int64_t n2, do
  * points that have no `path` argument (lvae_mmd_rbf_f32, lvae_kernel_sum_f32, lvae_mmd_perm_f32).
  * LVAE_MATH_FP32 (default): fp32 MFMA.  LVAE_MATH_BF16X3: three bf16 limbs per fp32 value, six limb products on
  * the bf16 matrix pipe, fp32 accumulate (fp32-equivalent results) wherever the kernel supports it (D <= 64;
- * larger D silently stays on fp32).  Read when a call is issued; not meant to be flipped while calls of other
+ * wider latents silently stay on fp32; the kernel sums contract D / 2 steps, so D <= 128 there).  Read when a call is issued; not meant to be flipped while calls of other
  * threads are being issued. */
 #define LVAE_MATH_FP32 0
 #define LVAE_MATH_BF16X3 1

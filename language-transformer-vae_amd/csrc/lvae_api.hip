@@ -44,10 +44,12 @@ int lvae_launch_latent_sums(const float* z, const float* mu, const float* logvar
 
 int lvae_launch_pair_mfma(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                           float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
-                          bool excl, int64_t excl_offset, int epi, const int* redo_flags, int sym, hipStream_t st);
+                          bool excl, int64_t excl_offset, int epi, const int* redo_flags, int sym, const float* colnorm,
+                          hipStream_t st);
 int lvae_launch_pair_bf16x3(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                           float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
-                          bool excl, int64_t excl_offset, int epi, const int* redo_flags, int sym, hipStream_t st);
+                          bool excl, int64_t excl_offset, int epi, const int* redo_flags, int sym, const float* colnorm,
+                          hipStream_t st);
 int lvae_launch_finalize_ksum(const double* partial, int nsplit, int64_t cpad, int64_t C, double* out,
                               hipStream_t st);
 int lvae_launch_kl(const float* mu, const float* logvar, int64_t n, int D, float lambda, float* kl_elem,
@@ -69,7 +71,7 @@ int lvae_launch_ksum_columns(const double* partial, int nsplit, int64_t cpad, in
                              hipStream_t st);
 int lvae_launch_pair_mfma_perm(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                                float2* partial, const PairHeader* hdr, int64_t excl_offset, int epi,
-                               const PermArgs& pa, int sym, hipStream_t st);
+                               const PermArgs& pa, int sym, const float* colnorm, hipStream_t st);
 int lvae_launch_prep_labels(const unsigned char* labels, int P, int64_t n, int64_t nblk, void* out,
                             hipStream_t st);
 int lvae_launch_perm_lr(const double* partial, const double* diag_partial, int nsplit, int64_t cpad, int64_t C,
@@ -112,7 +114,7 @@ int lvae_launch_ks_2samp(const float* a, int64_t n1, const float* b, int64_t n2,
 bool lvae_bf16x3_supported(int DP);
 int lvae_launch_pair_bf16x3_perm(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                                  float2* partial, const PairHeader* hdr, int64_t excl_offset, int epi,
-                                 const PermArgs& pa, int sym, hipStream_t st);
+                                 const PermArgs& pa, int sym, const float* colnorm, hipStream_t st);
 int lvae_launch_prep_bf16x3(int src, bool frag, const float* x, const float* spread, int spread_kind,
                             int64_t n, int64_t npad, int D, int DP, const PairHeader* hdr, int64_t ngauss,
                             void* out, hipStream_t st);
@@ -319,7 +321,7 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     hipEvent_t prof_stop = prof_mark(st, nullptr);
     if (need_mfma) {
         rc = launch_pair(p, rfrag, rbias, cop, partial, hdr, limit, 0, exclude_diag != 0, diag_offset,
-                         fixed_ref ? 4 : 0, nullptr, 0, st);
+                         fixed_ref ? 4 : 0, nullptr, 0, nullptr, st);
         if (rc) return rc;
     }
     if (need_direct) {
@@ -340,7 +342,7 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
             if (rc) return rc;
             if (fixed_ref) {
                 rc = launch_pair(p, rfrag, rbias, cop, partial, hdr, limit, 0, exclude_diag != 0, diag_offset, 0,
-                                 redo, 0, st);
+                                 redo, 0, nullptr, st);
                 if (rc) return rc;
                 rc = lvae_launch_finalize(partial, p.nsplit, p.cpad, M, nullptr, log_norm, log_qz, row_max,
                                           row_sum, hdr, limit, 0, 1, nullptr, redo, group_cols, st);
@@ -768,6 +770,9 @@ extern "C" int lvae_ks_2samp_f32(const float* a, int64_t n1, const float* b, int
     return lvae_launch_ks_2samp(a, n1, b, n2, out, ws, (hipStream_t)stream);
 }
 
+// The kernel sums contract two dimensions per MFMA step (norms enter as biases): their plans are made for D / 2.
+static inline int ksum_plan_dim(int D) { return (D + 1) / 2; }
+
 // ---- MMD -----------------------------------------------------------------------------------------------
 // Splits the bandwidth list into (count of zeros, KsumParams for the positive ones).  If the positive
 // alphas are all integer multiples (<= LVAE_KSUM_MAX) of the smallest one the sum of exponentials is a
@@ -817,7 +822,7 @@ extern "C" int lvae_mmd_workspace_bytes(int64_t n1, int64_t n2, int D, int64_t* 
     LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
     LVAE_CHECK_ARG(n1 >= 2 && n2 >= 2 && D >= 1, "need n1, n2 >= 2 and D >= 1");
     const int64_t nm = n1 > n2 ? n1 : n2;
-    const PairPlan p = lvae_make_pair_plan(nm, nm, D, false, 0, true);
+    const PairPlan p = lvae_make_pair_plan(nm, nm, ksum_plan_dim(D), false, 0, true);
     *out_bytes = (int64_t)(p.total + 256);
     return LVAE_OK;
 }
@@ -844,22 +849,26 @@ static bool ksum_use_bx(const PairPlan& p) {
     return g_pair_math.load() == LVAE_MATH_BF16X3 && lvae_bf16x3_supported(p.DP);
 }
 
-// Operands of a kernel-sum pass: reduced axis = points b (POINT rows, fragment-major, + |b|^2 biases), kept
-// axis = points a (SAMPLE rows).  bx: the limb operands replace the fp32 ones in the same regions.
+// Operands of a kernel-sum pass: reduced axis = points b (linear-only POINT rows -2b, fragment-major, + |b|^2
+// biases), kept axis = points a (linear-only SAMPLE rows, + |a|^2 into colnorm).  bx: the limb operands replace
+// the fp32 ones in the same regions (the fp32 prep still writes the biases and the norms).
 static int prep_ksum_operands(const PairPlan& p, bool bx, const float* a, int64_t na, const float* b, int64_t nb,
-                              int D, PairHeader* hdr, float* rfrag, float* rbias, float* cop, hipStream_t st) {
-    int rc = lvae_launch_prep(2, true, b, nullptr, 0, nb, p.nblk * 32, D, p.DP, hdr, 1, bx ? nullptr : rfrag, rbias,
+                              int D, PairHeader* hdr, float* rfrag, float* rbias, float* cop, float* colnorm,
+                              hipStream_t st) {
+    int rc = lvae_launch_prep(3, true, b, nullptr, 0, nb, p.nblk * 32, D, p.DP, hdr, 1, bx ? nullptr : rfrag, rbias,
                               nullptr, p.DC, st);
     if (rc) return rc;
-    if (!bx) return lvae_launch_prep(1, false, a, nullptr, 0, na, p.cpad, D, p.DP, hdr, 1, cop, nullptr, nullptr, p.DC, st);
-    rc = lvae_launch_prep_bf16x3(2, true, b, nullptr, 0, nb, p.nblk * 32, D, p.DP, hdr, 1, rfrag, st);
+    rc = lvae_launch_prep(4, false, a, nullptr, 0, na, p.cpad, D, p.DP, hdr, 1, bx ? nullptr : cop, colnorm, nullptr,
+                          p.DC, st);
+    if (rc || !bx) return rc;
+    rc = lvae_launch_prep_bf16x3(3, true, b, nullptr, 0, nb, p.nblk * 32, D, p.DP, hdr, 1, rfrag, st);
     if (rc) return rc;
-    return lvae_launch_prep_bf16x3(1, false, a, nullptr, 0, na, p.cpad, D, p.DP, hdr, 1, cop, st);
+    return lvae_launch_prep_bf16x3(4, false, a, nullptr, 0, na, p.cpad, D, p.DP, hdr, 1, cop, st);
 }
 
 static int ksum_pass(const float* a, int64_t na, const float* b, int64_t nb, int D, bool excl, int epi,
                      void* ws, double* out, hipStream_t st) {
-    const PairPlan p = lvae_make_pair_plan(nb, na, D, false, 0, a == b);
+    const PairPlan p = lvae_make_pair_plan(nb, na, ksum_plan_dim(D), false, 0, a == b);
     char* base = (char*)ws;
     PairHeader* hdr = (PairHeader*)(base + p.off_hdr);
     float* rfrag = (float*)(base + p.off_rfrag);
@@ -867,14 +876,15 @@ static int ksum_pass(const float* a, int64_t na, const float* b, int64_t nb, int
     float* cop = (float*)(base + p.off_cop);
     float2* partial = (float2*)(base + p.off_partial);
     int rc;
-    if (p.DP == 0) {      // D > 128: direct differences on the vector ALU (no symmetric walk)
+    if (p.DP == 0) {      // D > 256: direct differences on the vector ALU (no symmetric walk)
         rc = lvae_launch_ksum_wide(a, b, na, nb, D, hdr, excl, 0, p.nsplit, p.cpad, (double*)partial, st);
     } else {
         const bool bx = ksum_use_bx(p);
-        rc = prep_ksum_operands(p, bx, a, na, b, nb, D, hdr, rfrag, rbias, cop, st);
+        float* colnorm = (float*)(base + p.off_colbias);
+        rc = prep_ksum_operands(p, bx, a, na, b, nb, D, hdr, rfrag, rbias, cop, colnorm, st);
         if (rc) return rc;
         rc = (bx ? lvae_launch_pair_bf16x3 : lvae_launch_pair_mfma)(p, rfrag, rbias, cop, partial, hdr, -1.f, 0, excl,
-                                                                    0, epi, nullptr, a == b ? 1 : 0, st);
+                                                                    0, epi, nullptr, a == b ? 1 : 0, colnorm, st);
     }
     if (rc) return rc;
     return lvae_launch_finalize_ksum((const double*)partial, p.nsplit, p.cpad, na, out, st);
@@ -893,7 +903,7 @@ extern "C" int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int6
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int64_t nm = n1 > n2 ? n1 : n2;
-    const PairPlan pmax = lvae_make_pair_plan(nm, nm, D, false, 0, true);
+    const PairPlan pmax = lvae_make_pair_plan(nm, nm, ksum_plan_dim(D), false, 0, true);
     rc = check_ws(ws, ws_bytes, pmax.total + 256);
     if (rc) return rc;
     PairHeader* hdr = (PairHeader*)ws;
@@ -919,7 +929,7 @@ extern "C" int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int6
 extern "C" int lvae_kernel_sum_workspace_bytes(int64_t na, int64_t nb, int D, int64_t* out_bytes) {
     LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
     LVAE_CHECK_ARG(na >= 1 && nb >= 1 && D >= 1, "need na, nb, D >= 1");
-    const PairPlan p = lvae_make_pair_plan(nb, na, D, false, 0, true);     // the finer (symmetric) plan is the larger
+    const PairPlan p = lvae_make_pair_plan(nb, na, ksum_plan_dim(D), false, 0, true);     // the finer (symmetric) plan is the larger
     *out_bytes = (int64_t)p.total;
     return LVAE_OK;
 }
@@ -941,7 +951,7 @@ extern "C" int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, i
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int sym = symmetric != 0;
-    const PairPlan p = lvae_make_pair_plan(nb, na, D, false, 0, sym);
+    const PairPlan p = lvae_make_pair_plan(nb, na, ksum_plan_dim(D), false, 0, sym);
     rc = check_ws(ws, ws_bytes, p.total);
     if (rc) return rc;
     char* base = (char*)ws;
@@ -953,19 +963,20 @@ extern "C" int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, i
     if (kp.n == 0 && kp.c[0] == 0.f) {      // only alpha = 0 bandwidths: no pair kernel needed
         LVAE_HIP(hipMemsetAsync(partial, 0, (size_t)p.nsplit * p.cpad * sizeof(double), st));
     } else {
-        if (p.DP == 0) {  // D > 128: direct differences on the vector ALU; every pair of the owned rows is evaluated
+        if (p.DP == 0) {  // D > 256: direct differences on the vector ALU; every pair of the owned rows is evaluated
                           // (a symmetric request is served as a plain one: the owners' totals still add up)
             rc = lvae_launch_ksum_wide(a, b, na, nb, D, hdr, exclude_diag != 0, diag_offset, p.nsplit, p.cpad,
                                        (double*)partial, st);
             if (rc) return rc;
         } else {
             const bool bx = ksum_use_bx(p);
+            float* colnorm = (float*)(base + p.off_colbias);
             rc = prep_ksum_operands(p, bx, a, na, b, nb, D, hdr, (float*)(base + p.off_rfrag),
-                                    (float*)(base + p.off_rbias), (float*)(base + p.off_cop), st);
+                                    (float*)(base + p.off_rbias), (float*)(base + p.off_cop), colnorm, st);
             if (rc) return rc;
             rc = (bx ? lvae_launch_pair_bf16x3 : lvae_launch_pair_mfma)(
                 p, (float*)(base + p.off_rfrag), (float*)(base + p.off_rbias), (float*)(base + p.off_cop), partial,
-                hdr, -1.f, 0, exclude_diag != 0, diag_offset, ksum_epi(kp), nullptr, sym, st);
+                hdr, -1.f, 0, exclude_diag != 0, diag_offset, ksum_epi(kp), nullptr, sym, colnorm, st);
             if (rc) return rc;
         }
     }
@@ -981,7 +992,7 @@ static size_t perm_diag_bytes(const PairPlan& p) { return lvae_align256((size_t)
 extern "C" int lvae_mmd_perm_workspace_bytes(int64_t nc, int64_t n, int D, int64_t* out_bytes) {
     LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
     LVAE_CHECK_ARG(nc >= 1 && n >= 2 && D >= 1, "need nc >= 1, n >= 2, D >= 1");
-    const PairPlan p = lvae_make_pair_plan(n, nc, D, false, 1, true);
+    const PairPlan p = lvae_make_pair_plan(n, nc, ksum_plan_dim(D), false, 1, true);
     *out_bytes = (int64_t)(p.total + perm_labfrag_bytes(p) + perm_diag_bytes(p) + 256 * sizeof(double));
     return LVAE_OK;
 }
@@ -993,7 +1004,7 @@ extern "C" int lvae_mmd_perm_f32(const float* cols, int64_t nc, int64_t col_offs
     LVAE_CHECK_ARG(cols && pooled && labels && out, "cols, pooled, labels and out must be non-NULL");
     LVAE_CHECK_ARG(n >= 2 && nc >= 1 && col_offset >= 0 && col_offset + nc <= n,
                    "need n >= 2 and 0 <= col_offset, col_offset + nc <= n");
-    LVAE_CHECK_ARG(D >= 1 && D <= 128, "the MMD path needs 1 <= D <= 128 (got %d)", D);
+    LVAE_CHECK_ARG(D >= 1 && D <= 256, "the permutation test needs 1 <= D <= 256 (got %d)", D);
     LVAE_CHECK_ARG(n < (1LL << 31), "n must be below 2^31");
     LVAE_CHECK_ARG(P >= 1 && P <= 128, "need 1 <= P <= 128 labelings per call (got %d)", P);
     LVAE_CHECK_ARG(!symmetric || col_offset % 32 == 0, "symmetric evaluation needs col_offset %% 32 == 0");
@@ -1003,8 +1014,8 @@ extern "C" int lvae_mmd_perm_f32(const float* cols, int64_t nc, int64_t col_offs
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int sym = symmetric != 0;
-    const PairPlan p = lvae_make_pair_plan(n, nc, D, false, 1, sym);
-    const PairPlan pmax = lvae_make_pair_plan(n, nc, D, false, 1, true);
+    const PairPlan p = lvae_make_pair_plan(n, nc, ksum_plan_dim(D), false, 1, sym);
+    const PairPlan pmax = lvae_make_pair_plan(n, nc, ksum_plan_dim(D), false, 1, true);
     const size_t lab_bytes = perm_labfrag_bytes(p);
     const size_t diag_bytes = perm_diag_bytes(p);
     rc = check_ws(ws, ws_bytes, pmax.total + perm_labfrag_bytes(pmax) + perm_diag_bytes(pmax) + 256 * sizeof(double));
@@ -1026,8 +1037,9 @@ extern "C" int lvae_mmd_perm_f32(const float* cols, int64_t nc, int64_t col_offs
     rc = lvae_launch_prep_labels(labels, P, n, p.nblk, labfrag, st);
     if (rc) return rc;
     const bool bx = ksum_use_bx(p);
+    float* colnorm = (float*)(base + p.off_colbias);
     rc = prep_ksum_operands(p, bx, cols, nc, pooled, n, D, hdr, (float*)(base + p.off_rfrag),
-                            (float*)(base + p.off_rbias), (float*)(base + p.off_cop), st);
+                            (float*)(base + p.off_rbias), (float*)(base + p.off_cop), colnorm, st);
     if (rc) return rc;
     PermArgs pa{};
     pa.labfrag = labfrag;
@@ -1040,7 +1052,7 @@ extern "C" int lvae_mmd_perm_f32(const float* cols, int64_t nc, int64_t col_offs
     pa.P = P;
     rc = (bx ? lvae_launch_pair_bf16x3_perm : lvae_launch_pair_mfma_perm)(
         p, (float*)(base + p.off_rfrag), (float*)(base + p.off_rbias), (float*)(base + p.off_cop), partial, hdr,
-        col_offset, ksum_epi(kp), pa, sym, st);
+        col_offset, ksum_epi(kp), pa, sym, colnorm, st);
     if (rc) return rc;
     return lvae_launch_perm_lr((const double*)partial, diag_partial, p.nsplit, p.cpad, nc, labels, n, col_offset,
                                P, sym, qperm, out, st);

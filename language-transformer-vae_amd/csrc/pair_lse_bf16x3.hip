@@ -9,8 +9,9 @@
 // ---- operand preparation ------------------------------------------------------------------------------
 // One thread per (row, step of 8 dimensions, k-half): computes the eight fp32 operand values of that half
 // (SRC 0, GAUSS rows: a_d or b_d; SRC 1, SAMPLE rows: z_d^2 or z_d; SRC 2, POINT rows: 1 or -2 y_d -- the
-// same values, after the same centering shift, as prep_operand_kernel of the fp32 path) and writes their
-// three limbs as 16-byte vectors.
+// same values, after the same centering shift, as prep_operand_kernel of the fp32 path; SRC 3 / 4, the
+// linear-only operands of the kernel sums: -2 y_d / x_d with sixteen dimensions per step, DP = padded D / 2)
+// and writes their three limbs as 16-byte vectors.
 //   FRAG (reduced axis): out[blk][step][limb][lane = row%32 + 32*half][8]           (16 B per lane)
 //   else (kept axis)   : out[row][half][step][limb][8]
 // The row bias (GAUSS) and the header statistics are produced by the fp32 prep kernel, which runs anyway
@@ -22,6 +23,7 @@ prep_bf16x3_kernel(const float* __restrict__ x, const float* __restrict__ spread
                    uint4* __restrict__ out) {
     constexpr bool GAUSS = SRC == 0;
     constexpr bool POINT = SRC == 2;
+    constexpr bool LIN = SRC == 3 || SRC == 4;           // linear-only operands of the kernel sums: 16 dims per step
     const int NS = DP / 8;                               // MFMA steps
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = npad * NS * 2;
@@ -45,11 +47,13 @@ prep_bf16x3_kernel(const float* __restrict__ x, const float* __restrict__ spread
     if (row < n) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int d = 8 * step + e;
+            const int d = LIN ? 16 * step + 8 * half + e : 8 * step + e;
             float v = 0.f;
             if (d < D) {
-                const float xs = x[row * D + d] - (float)(hdr->colsum[d] * inv_ngauss);
-                if (GAUSS) {
+                const float xs = x[row * D + d] - (LIN ? 0.f : (float)(hdr->colsum[d] * inv_ngauss));
+                if (LIN) {
+                    v = SRC == 3 ? -2.0f * xs : xs;
+                } else if (GAUSS) {
                     const float sp = spread[row * D + d];
                     const float p = spread_kind == LVAE_SPREAD_VAR ? 1.0f / sp : expf(-sp);
                     v = half == 0 ? -0.5f * LVAE_LOG2E * p : LVAE_LOG2E * xs * p;
@@ -87,7 +91,8 @@ prep_bf16x3_kernel(const float* __restrict__ x, const float* __restrict__ spread
 // ---- host launchers ----------------------------------------------------------------------------------
 bool lvae_bf16x3_supported(int DP) { return DP == 16 || DP == 32 || DP == 64; }
 
-// src: 0 GAUSS, 1 SAMPLE, 2 POINT (as lvae_launch_prep); frag: reduced-axis (fragment-major) layout.
+// src: 0 GAUSS, 1 SAMPLE, 2 POINT, 3 / 4 linear-only POINT / SAMPLE (as lvae_launch_prep); frag: reduced-axis
+// (fragment-major) layout.
 int lvae_launch_prep_bf16x3(int src, bool frag, const float* x, const float* spread, int spread_kind,
                             int64_t n, int64_t npad, int D, int DP, const PairHeader* hdr, int64_t ngauss,
                             void* out, hipStream_t st) {
@@ -100,6 +105,8 @@ int lvae_launch_prep_bf16x3(int src, bool frag, const float* x, const float* spr
     if (src == 0 && frag) LVAE_PBX(0, true);
     else if (src == 2 && frag) LVAE_PBX(2, true);
     else if (src == 1 && !frag) LVAE_PBX(1, false);
+    else if (src == 3 && frag) LVAE_PBX(3, true);
+    else if (src == 4 && !frag) LVAE_PBX(4, false);
     else return lvae_set_error(LVAE_ERR_INVALID, "bf16x3 prep: unsupported operand role");
 #undef LVAE_PBX
     LVAE_LAUNCH_CHECK();
@@ -109,13 +116,14 @@ int lvae_launch_prep_bf16x3(int src, bool frag, const float* x, const float* spr
 template <int DP, int NCB, int WPS>
 static int launch_bx(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                      float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
-                     bool excl, int64_t excl_offset, int epi, const int* redo_flags, int sym, hipStream_t st) {
+                     bool excl, int64_t excl_offset, int epi, const int* redo_flags, int sym, const float* colnorm,
+                    hipStream_t st) {
     const dim3 grid((unsigned)(p.cpad / (4 * 32 * NCB)), (unsigned)p.nsplit);
     const PermArgs pa{};
 #define LVAE_PAIR(X, E)                                                                                    \
     hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, NCB, WPS, X, E, false, true>), grid, dim3(256), 0, st, rfrag, \
                        rbias, cop, partial, hdr, cond_limit, use_if_above, p.nblk, p.blk_per_split, p.cpad,  \
-                       excl_offset, pa, redo_flags, sym)
+                       excl_offset, pa, redo_flags, sym, colnorm)
     switch (epi * 2 + (excl ? 1 : 0)) {
         case 0: LVAE_PAIR(false, 0); break;
         case 1: LVAE_PAIR(true, 0); break;
@@ -139,15 +147,17 @@ static int launch_bx(const PairPlan& p, const float* rfrag, const float* rbias, 
 int lvae_launch_pair_bf16x3(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                             float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
                             bool excl, int64_t excl_offset, int epi, const int* redo_flags, int sym,
-                            hipStream_t st) {
+                            const float* colnorm, hipStream_t st) {
+    if (epi >= 1 && epi <= 3 && !colnorm)
+        return lvae_set_error(LVAE_ERR_INVALID, "kernel-sum epilogues need the per-column norms");
     if (p.cpad % (4 * 32 * p.NCB) != 0)
         return lvae_set_error(LVAE_ERR_INVALID, "pair plan: cpad %lld not a multiple of the tile", (long long)p.cpad);
     if (p.NCB != (p.DP <= 32 ? 2 : 1))
         return lvae_set_error(LVAE_ERR_INVALID, "pair plan: the bf16x3 kernel needs NCB 2 at D <= 32, 1 at D = 64");
     switch (p.DP) {
-        case 16: return launch_bx<16, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, st);
-        case 32: return launch_bx<32, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, st);
-        case 64: return launch_bx<64, 1, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, st);
+        case 16: return launch_bx<16, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, colnorm, st);
+        case 32: return launch_bx<32, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, colnorm, st);
+        case 64: return launch_bx<64, 1, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, colnorm, st);
         default:
             return lvae_set_error(LVAE_ERR_UNSUPPORTED, "the bf16x3 path needs D <= 64 (got D=%d)", p.D);
     }
@@ -157,23 +167,23 @@ int lvae_launch_pair_bf16x3(const PairPlan& p, const float* rfrag, const float* 
 template <int DP, int WPS>
 static int launch_bx_perm(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                           float2* partial, const PairHeader* hdr, int64_t excl_offset, int epi,
-                          const PermArgs& pa, int sym, hipStream_t st) {
+                          const PermArgs& pa, int sym, const float* colnorm, hipStream_t st) {
     const dim3 grid((unsigned)(p.cpad / (4 * 32)), (unsigned)p.nsplit);
     if (epi == 1)
         hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 1, true, true>), grid, dim3(256), 0, st, rfrag,
                            rbias, cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr,
-                           sym);
+                           sym, colnorm);
     else
         hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 2, true, true>), grid, dim3(256), 0, st, rfrag,
                            rbias, cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr,
-                           sym);
+                           sym, colnorm);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }
 
 int lvae_launch_pair_bf16x3_perm(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                                  float2* partial, const PairHeader* hdr, int64_t excl_offset, int epi,
-                                 const PermArgs& pa, int sym, hipStream_t st) {
+                                 const PermArgs& pa, int sym, const float* colnorm, hipStream_t st) {
     if (sym && pa.col_offset % 32 != 0)
         return lvae_set_error(LVAE_ERR_INVALID, "symmetric permutation sums need col_offset %% 32 == 0");
     if (p.NCB != 1 || p.cpad % 128 != 0)
@@ -183,10 +193,11 @@ int lvae_launch_pair_bf16x3_perm(const PairPlan& p, const float* rfrag, const fl
                               "the permutation test needs bandwidths that are integer multiples (<= 16) of the "
                               "smallest one");
     if (pa.P < 1 || pa.P > 128) return lvae_set_error(LVAE_ERR_INVALID, "need 1 <= labelings <= 128 per pass");
+    if (!colnorm) return lvae_set_error(LVAE_ERR_INVALID, "kernel-sum epilogues need the per-column norms");
     switch (p.DP) {
-        case 16: return launch_bx_perm<16, 2>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, st);
-        case 32: return launch_bx_perm<32, 2>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, st);
-        case 64: return launch_bx_perm<64, 1>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, st);
+        case 16: return launch_bx_perm<16, 2>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, colnorm, st);
+        case 32: return launch_bx_perm<32, 2>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, colnorm, st);
+        case 64: return launch_bx_perm<64, 1>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, colnorm, st);
         default:
             return lvae_set_error(LVAE_ERR_UNSUPPORTED, "the bf16x3 path needs D <= 64 (got D=%d)", p.D);
     }

@@ -56,8 +56,9 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 #define LSE_MINIT (-1.0e30f)
 
 // EPI 0 / 4: streaming logsumexp (log q(z), q_z_estimate, MI bounds), see above.
-// EPI 1-3: kernel-matrix column sums.  The contraction is the squared distance d2 = |x - y|^2 (POINT x
-//        SAMPLE operands) and every pair contributes f(d2) = sum_k exp(-alpha_k * (eps + |d2|)),
+// EPI 1-3: kernel-matrix column sums.  The contraction is -2 x.y (POINT x SAMPLE operands, two dimensions per
+//        MFMA step), the squared distance d2 = |x|^2 + |y|^2 - 2 x.y is completed by the row bias |y|^2 and
+//        the per-column |x|^2, and every pair contributes f(d2) = sum_k exp(-alpha_k * (eps + |d2|)),
 //        accumulated per column in float64 (one tile's 16 terms are first summed in float32).
 //        EPI 1: one bandwidth; EPI 2: alpha_k = base * (integer <= 16), f is a polynomial in
 //        t = exp(-base*v) evaluated by Horner's rule on the packed fp32 pipe (one v_exp_f32 per pair for
@@ -80,7 +81,8 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
                      const float* __restrict__ cop, float2* __restrict__ partial,
                      const PairHeader* __restrict__ hdr, float cond_limit, int use_if_above,
                      int64_t nblk, int64_t blk_per_split, int64_t cpad, int64_t excl_offset,
-                     PermArgs pa, const int* __restrict__ redo_flags, int sym) {
+                     PermArgs pa, const int* __restrict__ redo_flags, int sym,
+                     const float* __restrict__ colnorm) {
     static_assert(!PERM || (NCB == 1 && (EPI == 1 || EPI == 2)), "PERM needs NCB == 1 and a polynomial epilogue");
     static_assert(!BX || DP <= 64, "the split-bf16 contraction is built for D <= 64");
     // Path gate: the conditioning estimate written by prep decides between this kernel and the direct
@@ -276,9 +278,15 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
 #pragma unroll
         for (int k = 0; k < KC; ++k) kc[k] = kp->c[k];
     }
+    // Kernel sums contract the LINEAR part of the squared distance only: the operands hold two dimensions per
+    // fp32 MFMA step (POINT rows -2y against SAMPLE rows x; DP is the padded HALF dimension), the reduced
+    // element's |y|^2 is the row bias and the kept element's |x|^2 (colnorm, one value per lane) is added here.
+    float cn[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) cn[cb] = (EPI >= 1 && EPI <= 3) ? colnorm[col0 + cb * 32 + r] : 0.f;
     // two kernel values at a time (packed fp32 for the polynomial)
-    auto kfun2 = [&](float d2a, float d2b) -> f32x2 {
-        const f32x2 v = {fabsf(d2a) + k_eps, fabsf(d2b) + k_eps};
+    auto kfun2 = [&](float d2a, float d2b, float cnv) -> f32x2 {
+        const f32x2 v = {fabsf(d2a + cnv) + k_eps, fabsf(d2b + cnv) + k_eps};
         if (EPI == 1 || EPI == 2) {
             const f32x2 a = v * (f32x2){k_nbase, k_nbase};
             f32x2 t;
@@ -310,7 +318,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
             kt2[cb] += e;
         } else if (EPI >= 1) {
             if (ms < 8) {
-                const f32x2 kval = kfun2(prev[cb][2 * ms], prev[cb][2 * ms + 1]);
+                const f32x2 kval = kfun2(prev[cb][2 * ms], prev[cb][2 * ms + 1], cn[cb]);
                 if (ms == 0) kt2[cb] = kval;
                 else kt2[cb] += kval;
                 if (PERM) {

@@ -4,13 +4,14 @@
 template <int DP, int NCB, int WPS>
 static int launch_t(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                     float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
-                    bool excl, int64_t excl_offset, int epi, const int* redo_flags, int sym, hipStream_t st) {
+                    bool excl, int64_t excl_offset, int epi, const int* redo_flags, int sym, const float* colnorm,
+                    hipStream_t st) {
     const dim3 grid((unsigned)(p.cpad / (4 * 32 * NCB)), (unsigned)p.nsplit);
     const PermArgs pa{};
 #define LVAE_PAIR(X, E)                                                                              \
     hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, NCB, WPS, X, E>), grid, dim3(256), 0, st, rfrag, rbias, \
                        cop, partial, hdr, cond_limit, use_if_above, p.nblk, p.blk_per_split, p.cpad,  \
-                       excl_offset, pa, redo_flags, sym)
+                       excl_offset, pa, redo_flags, sym, colnorm)
     switch (epi * 2 + (excl ? 1 : 0)) {
         case 0: LVAE_PAIR(false, 0); break;
         case 1: LVAE_PAIR(true, 0); break;
@@ -34,20 +35,24 @@ static int launch_t(const PairPlan& p, const float* rfrag, const float* rbias, c
 // the row biases; 1/2/3: kernel-matrix column sums (float64 partials; parameters in hdr->ksum: single
 // bandwidth / polynomial of degree <= 16 / arbitrary bandwidths).
 // redo_flags (may be NULL): one int per workgroup column group; workgroups whose flag is 0 exit.
+// colnorm (epi 1/2/3 only, else NULL): |x_c|^2 per kept element, see the kernel.
 // sym != 0 (epi 1/2/3 only; the kept elements are rows excl_offset.. of the reduced sample, excl_offset a
 // multiple of 32): visit the upper
 // triangle of tiles only; the TOTAL over columns is that of the full matrix, the per-column sums are not.
 int lvae_launch_pair_mfma(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                           float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
-                          bool excl, int64_t excl_offset, int epi, const int* redo_flags, int sym, hipStream_t st) {
+                          bool excl, int64_t excl_offset, int epi, const int* redo_flags, int sym, const float* colnorm,
+                    hipStream_t st) {
     if (p.cpad % (4 * 32 * p.NCB) != 0)
         return lvae_set_error(LVAE_ERR_INVALID, "pair plan: cpad %lld not a multiple of the tile",
                               (long long)p.cpad);
+    if (epi >= 1 && epi <= 3 && !colnorm)
+        return lvae_set_error(LVAE_ERR_INVALID, "kernel-sum epilogues need the per-column norms");
     switch (p.DP) {
-        case 16: return launch_t<16, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, st);
-        case 32: return launch_t<32, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, st);
-        case 64: return launch_t<64, 1, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, st);
-        case 128: return launch_t<128, 1, 1>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, st);
+        case 16: return launch_t<16, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, colnorm, st);
+        case 32: return launch_t<32, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, colnorm, st);
+        case 64: return launch_t<64, 1, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, colnorm, st);
+        case 128: return launch_t<128, 1, 1>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, colnorm, st);
         default:
             return lvae_set_error(LVAE_ERR_UNSUPPORTED, "MFMA path needs D <= 128 (got D=%d)", p.D);
     }
@@ -58,7 +63,7 @@ int lvae_launch_pair_lse_mfma(const PairPlan& p, const float* rfrag, const float
                               float cond_limit, int use_if_above, bool excl, int64_t excl_offset,
                               hipStream_t st) {
     return lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl,
-                                 excl_offset, 0, nullptr, 0, st);
+                                 excl_offset, 0, nullptr, 0, nullptr, st);
 }
 
 // Kernel-matrix column sums plus label-permutation sums (see PERM above); diagonal pairs (reduced row ==
@@ -66,21 +71,21 @@ int lvae_launch_pair_lse_mfma(const PairPlan& p, const float* rfrag, const float
 template <int DP, int WPS>
 static int launch_perm_t(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                          float2* partial, const PairHeader* hdr, int64_t excl_offset, int epi,
-                         const PermArgs& pa, int sym, hipStream_t st) {
+                         const PermArgs& pa, int sym, const float* colnorm, hipStream_t st) {
     const dim3 grid((unsigned)(p.cpad / (4 * 32)), (unsigned)p.nsplit);
     if (epi == 1)
         hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 1, true>), grid, dim3(256), 0, st, rfrag, rbias,
-                           cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr, sym);
+                           cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr, sym, colnorm);
     else
         hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 2, true>), grid, dim3(256), 0, st, rfrag, rbias,
-                           cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr, sym);
+                           cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr, sym, colnorm);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }
 
 int lvae_launch_pair_mfma_perm(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                                float2* partial, const PairHeader* hdr, int64_t excl_offset, int epi,
-                               const PermArgs& pa, int sym, hipStream_t st) {
+                               const PermArgs& pa, int sym, const float* colnorm, hipStream_t st) {
     if (sym && pa.col_offset % 32 != 0)
         return lvae_set_error(LVAE_ERR_INVALID, "symmetric permutation sums need col_offset %% 32 == 0");
     if (p.NCB != 1 || p.cpad % 128 != 0)
@@ -90,11 +95,12 @@ int lvae_launch_pair_mfma_perm(const PairPlan& p, const float* rfrag, const floa
                               "the permutation test needs bandwidths that are integer multiples (<= 16) of the "
                               "smallest one");
     if (pa.P < 1 || pa.P > 128) return lvae_set_error(LVAE_ERR_INVALID, "need 1 <= labelings <= 128 per pass");
+    if (!colnorm) return lvae_set_error(LVAE_ERR_INVALID, "kernel-sum epilogues need the per-column norms");
     switch (p.DP) {
-        case 16: return launch_perm_t<16, 2>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, st);
-        case 32: return launch_perm_t<32, 2>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, st);
-        case 64: return launch_perm_t<64, 1>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, st);
-        case 128: return launch_perm_t<128, 1>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, st);
+        case 16: return launch_perm_t<16, 2>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, colnorm, st);
+        case 32: return launch_perm_t<32, 2>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, colnorm, st);
+        case 64: return launch_perm_t<64, 1>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, colnorm, st);
+        case 128: return launch_perm_t<128, 1>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, colnorm, st);
         default:
             return lvae_set_error(LVAE_ERR_UNSUPPORTED, "MFMA path needs D <= 128 (got D=%d)", p.D);
     }

@@ -60,6 +60,9 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ m
 // is the squared distance |x - y|^2 (kernel-matrix sums; padded rows get +inf).  FRAG selects the fragment-major
 // reduced-axis layout (the 32 rows of a block at one q are 512 contiguous bytes; a wave writes 128-byte runs),
 // otherwise row-major [row][2*DP] for the kept axis.  `out` may be NULL (bias / header statistics only).
+// SRC 3 / 4 (kernel sums): linear-only operands with TWO dimensions per MFMA step (DP = padded D / 2): POINT
+// rows -2y (k-half 0: dimension 2s, k-half 1: dimension 2s + 1) with bias |y|^2 (+inf on padded rows), SAMPLE
+// rows x with `bias` receiving |x|^2 (the per-column norm the epilogue adds); no centering shift.
 #define PREP_RB 4
 template <int SRC, bool FRAG>
 __global__ void __launch_bounds__(1024)
@@ -69,11 +72,12 @@ prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ sprea
                     int DC) {
     constexpr bool GAUSS = SRC == 0;
     constexpr bool POINT = SRC == 2;
+    constexpr bool LIN = SRC == 3 || SRC == 4;
     __shared__ float sm_shift[128];
     __shared__ float sm_w[16][3];
     const int NQ = DP >> 2;                    // 4, 8, 16 or 32 lanes per row
     const int tid = threadIdx.x;
-    if (tid < DP) sm_shift[tid] = tid < D ? (float)(hdr->colsum[tid] * inv_ngauss) : 0.f;
+    if (!LIN && tid < DP) sm_shift[tid] = tid < D ? (float)(hdr->colsum[tid] * inv_ngauss) : 0.f;
     __syncthreads();
     const int r = tid / NQ;
     const int q = tid % NQ;
@@ -86,7 +90,19 @@ prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ sprea
         const bool valid = row < n;
         f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
         float csum = 0.f, cond = 0.f, nsum = 0.f;
-        if (valid) {
+        if (LIN) {
+            if (valid) {      // eight consecutive dimensions of the row: pairs (2s, 2s + 1) for the four steps 4q .. 4q + 3
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int d = 8 * q + 2 * e;
+                    const float x0 = d < D ? x[row * D + d] : 0.f;
+                    const float x1 = d + 1 < D ? x[row * D + d + 1] : 0.f;
+                    v0[e] = SRC == 3 ? -2.0f * x0 : x0;
+                    v1[e] = SRC == 3 ? -2.0f * x1 : x1;
+                    csum += x0 * x0 + x1 * x1;
+                }
+            }
+        } else if (valid) {
             f32x4 xv4 = {0.f, 0.f, 0.f, 0.f}, sp4 = xv4;
             if (vec) {
                 xv4 = *reinterpret_cast<const f32x4*>(x + row * D + 4 * q);
@@ -152,8 +168,8 @@ prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ sprea
                 nsum += __shfl_xor(nsum, off, 64);
             }
             if (bias && q == 0 && row < npad) {
-                float bv = GAUSS ? -0.5f * LVAE_LOG2E * csum : (POINT ? csum : 0.f);
-                if (!valid) bv = FRAG ? (POINT ? INFINITY : -INFINITY) : 0.f;
+                float bv = GAUSS ? -0.5f * LVAE_LOG2E * csum : ((POINT || LIN) ? csum : 0.f);
+                if (!valid) bv = FRAG ? ((POINT || LIN) ? INFINITY : -INFINITY) : 0.f;
                 bias[row] = bv;
             }
             if (GAUSS && valid) {
@@ -329,7 +345,9 @@ int lvae_launch_prep(int src, bool frag, const float* x, const float* spread, in
 #define LVAE_PREP(S, F)                                                                          \
     hipLaunchKernelGGL((prep_operand_kernel<S, F>), grid, dim3(threads), 0, st, x, spread,        \
                        spread_kind, n, npad, D, DP, hdr, inv, out, bias, dparams, DC)
-    if (src == 0 && frag) LVAE_PREP(0, true);
+    if (src == 3 && frag) LVAE_PREP(3, true);
+    else if (src == 4 && !frag) LVAE_PREP(4, false);
+    else if (src == 0 && frag) LVAE_PREP(0, true);
     else if (src == 0) LVAE_PREP(0, false);
     else if (src == 1 && frag) LVAE_PREP(1, true);
     else if (src == 1) LVAE_PREP(1, false);
