@@ -292,8 +292,8 @@ int lvae_ks_2samp_f32(const float* a, int64_t n1, const float* b, int64_t n2, do
  * points that have no `path` argument (lvae_mmd_rbf_f32, lvae_kernel_sum_f32, lvae_mmd_perm_f32).
  * LVAE_MATH_FP32 (default): fp32 MFMA.  LVAE_MATH_BF16X3: three bf16 limbs per fp32 value, six limb products on
  * the bf16 matrix pipe, fp32 accumulate (fp32-equivalent results) wherever the kernel supports it (D <= 64;
- * wider latents silently stay on fp32; the kernel sums contract D / 2 steps, so D <= 128 there).  Read when a call is issued; not meant to be flipped while calls of other
- * threads are being issued. */
+ * wider latents silently stay on fp32; the kernel sums contract D / 2 steps, so D <= 128 there).  Read when a
+ * call is issued; not meant to be flipped while calls of other threads are being issued. */
 #define LVAE_MATH_FP32 0
 #define LVAE_MATH_BF16X3 1
 int lvae_set_pair_math(int mode);

@@ -92,11 +92,20 @@ prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ sprea
         float csum = 0.f, cond = 0.f, nsum = 0.f;
         if (LIN) {
             if (valid) {      // eight consecutive dimensions of the row: pairs (2s, 2s + 1) for the four steps 4q .. 4q + 3
+                float xr[8];
+                if ((D & 3) == 0 && 8 * q + 8 <= D) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(x + row * D + 8 * q);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(x + row * D + 8 * q + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { xr[e] = lo[e]; xr[4 + e] = hi[e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xr[e] = 8 * q + e < D ? x[row * D + 8 * q + e] : 0.f;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int d = 8 * q + 2 * e;
-                    const float x0 = d < D ? x[row * D + d] : 0.f;
-                    const float x1 = d + 1 < D ? x[row * D + d + 1] : 0.f;
+                    const float x0 = xr[2 * e];
+                    const float x1 = xr[2 * e + 1];
                     v0[e] = SRC == 3 ? -2.0f * x0 : x0;
                     v1[e] = SRC == 3 ? -2.0f * x1 : x1;
                     csum += x0 * x0 + x1 * x1;
