@@ -24,7 +24,7 @@ def run(n1, n2, D, P, iters=2):
     dp = (time.perf_counter() - t0) / iters
     n = n1 + n2
     print(f"MMD perm n1={n1} n2={n2} D={D} P={P}+1: {dt*1e3:.1f} ms  {n*n/dt:.3e} pooled entries/s "
-          f"({n*n*4*D/dt/157.3e12*100:.1f}% of fp32 MFMA peak on the distance part); statistic alone "
+          f"({0.5*n*n*2*D/dt/157.3e12*100:.1f}% of fp32 MFMA peak on the distance part: upper triangle, 2D flop per entry); statistic alone "
           f"{dp*1e3:.1f} ms; stat={float(out['statistic']):.3e} (plain {float(plain[0]):.3e}) pval={float(out['pval']):.3f}",
           flush=True)
 
