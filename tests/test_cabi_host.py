@@ -147,3 +147,27 @@ def test_grid_quantisation_of_multi_gpu_shapes():
         rounds = -(-groups * nsplit // 512)
         eff = (groups * nblk / 512) / (rounds * bps)
         assert eff > 0.95, (world, groups, nsplit, eff)
+
+
+def test_committed_bench_line_has_the_contract_keys():
+    """profiles/r01/bench_n1.json is the line bench.py printed on the MI355X: the driver's contract keys, the
+    roofline object and the CPU baseline must all be there, and the numbers must be self-consistent."""
+    import json
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r01", "bench_n1.json")).read())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["vs_baseline"] is None
+    assert line["dtype"] == "f32" and line["data"] == "synthetic" and "workload" in line["config"]
+    assert "model" not in line["config"]
+    r = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - r["flops_per_launch"] / (r["kernel_ms_avg"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+    c = line["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["unit"] == line["unit"]
+    n = line["config"]["N"]
+    assert abs(line["value"] - n * n / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
