@@ -247,15 +247,16 @@ def test_kernel_sum_blocks(na, nb, D, off):
 
 
 @pytest.mark.parametrize("n1,n2,D,P", [(300, 340, 32, 20), (257, 190, 64, 130), (1000, 1500, 16, 9),
-                                         (200, 150, 128, 5), (2048, 2048, 32, 33)])
+                                         (200, 150, 128, 5), (2048, 2048, 32, 33), (130, 110, 250, 7)])
 def test_mmd_permutation_test_unpinned(n1, n2, D, P):
     """Permutation statistics (PARITY UNPINNED, like the statistic itself) against the float64 NumPy
     restatement evaluated on the dense kernel matrix.  The statistic is a difference of O(1) means, so the
     error is judged against the kernel scale, and the observed statistic against 1e-4."""
     from lvae import estimators as E
     rng = np.random.default_rng(n1 + D + P)
-    a = rng.standard_normal((n1, D)).astype(np.float32)
-    b = (rng.standard_normal((n2, D)) * 0.9 + 0.15).astype(np.float32)
+    scale = 1.0 if D <= 128 else 4.0 / np.sqrt(D)        # keep the kernel values away from underflow at wide D
+    a = (rng.standard_normal((n1, D)) * scale).astype(np.float32)
+    b = ((rng.standard_normal((n2, D)) * 0.9 + 0.15) * scale).astype(np.float32)
     alphas = [0.1 * i for i in range(15)] if D != 64 else [0.02]
     ref_obs, K = onp.mmd_statistic_tts(a, b, alphas, ret_matrix=True)
     labels = E.permutation_labels(n1, n2, P, "cuda", torch.Generator(device="cuda").manual_seed(5))
