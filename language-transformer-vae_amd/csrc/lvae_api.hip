@@ -27,7 +27,11 @@ int lvae_launch_pair_lse_mfma(const PairPlan& p, const float* rfrag, const float
 int lvae_launch_pair_direct(const PairPlan& p, bool joint, bool pm, const float* z,
                             const float* dparams, float2* partial, float2* partial_pm, int* redo_flags,
                             const PairHeader* hdr, float cond_limit, int use_if_above, int excl,
-                            int64_t excl_offset, hipStream_t st);
+                            int64_t excl_offset, hipStream_t st, bool pm_fast_done = false);
+bool lvae_pm_bx_supported(int DC);
+int lvae_launch_pm_bx(const PairPlan& p, const float* z, const float* mu, const float* spread, int spread_kind,
+                      const PairHeader* hdr, void* aop, void* bop, float2* partial_pm, int* redo_flags,
+                      hipStream_t st);
 
 int lvae_launch_reduce(int mode, const float* x, int64_t n, double scale, double* out, double* part,
                        hipStream_t st);
@@ -326,9 +330,16 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     }
     if (need_direct) {
         const bool djoint = want_joint && joint_path != LVAE_PATH_MFMA;
+        // opt-in bf16x3 path: the prod-marginals polynomial runs on the bf16 matrix pipe too (D <= 32)
+        const bool pm_bx = bx && with_pm && p.DP && lvae_pm_bx_supported(p.DC);
+        if (pm_bx) {
+            rc = lvae_launch_pm_bx(p, z, mu, spread, spread_kind, hdr, base + p.off_pmbx_a, base + p.off_pmbx_b,
+                                   dpartial_pm, (int*)(base + p.off_dflags), st);
+            if (rc) return rc;
+        }
         rc = lvae_launch_pair_direct(p, djoint, with_pm, z, dparams, dpartial, dpartial_pm,
                                      (int*)(base + p.off_dflags), hdr, limit, 1,
-                                     exclude_diag, diag_offset, st);
+                                     exclude_diag, diag_offset, st, pm_bx);
         if (rc) return rc;
     }
     if (prof_stop) prof_mark(st, prof_stop);

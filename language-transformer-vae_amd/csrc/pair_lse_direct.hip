@@ -254,13 +254,14 @@ static int launch_pm(const PairPlan& p, const float* z, const float* dparams, fl
 }
 
 // joint: produce the log q(z) partials (gated on the conditioning estimate when cond_limit >= 0);
-// pm: produce the product-of-marginals partials (never gated).
+// pm: produce the product-of-marginals partials (never gated); pm_fast_done: the fast pass has been run by
+// lvae_launch_pm_bx (same partial layout, same flags), only the redo of flagged waves is launched here.
 // The direct parameters are padded (w = b = 0, a zero term) to DC columns: 16/32/64 for D <= 64, where
 // the kernels keep the whole latent row in registers, else a multiple of 16.
 int lvae_launch_pair_direct(const PairPlan& p, bool joint, bool pm, const float* z,
                             const float* dparams, float2* partial, float2* partial_pm, int* redo_flags,
                             const PairHeader* hdr, float cond_limit, int use_if_above, int excl,
-                            int64_t excl_offset, hipStream_t st) {
+                            int64_t excl_offset, hipStream_t st, bool pm_fast_done) {
     if (p.cpad % 256 != 0)
         return lvae_set_error(LVAE_ERR_INVALID, "pair plan: cpad %lld not a multiple of 256",
                               (long long)p.cpad);
@@ -282,7 +283,7 @@ int lvae_launch_pair_direct(const PairPlan& p, bool joint, bool pm, const float*
     if (pm) {
         // per-dimension states are independent: latent rows wider than 32 are swept in 32-wide chunks
         int zper = DC >= 32 ? 2 : 1;
-        for (int d0 = 0; d0 < DC; d0 += 32) {
+        for (int d0 = 0; d0 < DC && !pm_fast_done; d0 += 32) {   // (pm_fast_done: another kernel wrote partials + flags)
             if (DC - d0 >= 32) rc = launch_pm<32>(p, z, dparams, partial_pm, redo_flags, d0, st);
             else rc = launch_pm<16>(p, z, dparams, partial_pm, redo_flags, d0, st);
             if (rc != LVAE_OK) return rc;

@@ -61,7 +61,7 @@ struct PairPlan {
     int DC;          // padded dim of the direct-path parameters: 16/32/64, or a multiple of 16 above
     // byte offsets into the workspace
     size_t off_hdr, off_rfrag, off_rbias, off_cop, off_colbias, off_partial;
-    size_t off_dparams, off_dpartial, off_dpartial_pm, off_dflags, off_pmtmp, off_redo, total;
+    size_t off_dparams, off_dpartial, off_dpartial_pm, off_dflags, off_pmtmp, off_redo, off_pmbx_a, off_pmbx_b, total;
 };
 
 static inline size_t lvae_align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -121,7 +121,8 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
         if (ds > R / 128) ds = R / 128;
         if (ds > 64) ds = 64;
         if (ds < 1) ds = 1;
-        p.rows_per_dsplit = lvae_ceil_div(R, ds);
+        p.rows_per_dsplit = lvae_round_up(lvae_ceil_div(R, ds), 32);    // whole 32-row blocks (the bf16 prod-marginals
+                                                                        // kernel streams blocks; same ranges for its redo)
         p.dsplit = (int)lvae_ceil_div(R, p.rows_per_dsplit);
     }
     p.DC = D <= 16 ? 16 : (D <= 32 ? 32 : (D <= 64 ? 64 : (int)lvae_round_up(D, 16)));
@@ -144,6 +145,11 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
     if (with_pm) o = lvae_align256(o + (size_t)p.DC * p.cpad * sizeof(float));
     p.off_redo = o;     // redo flags of the fixed-reference logsumexp pass: one int per MFMA workgroup column group
     o = lvae_align256(o + (size_t)(p.cpad / 128 + 1) * sizeof(int));
+    // limb operands of the experimental bf16 prod-marginals kernel (pair_pm_bx.hip): 1 KiB per posterior / sample
+    p.off_pmbx_a = o;
+    if (with_pm && p.DC <= 32) o = lvae_align256(o + (size_t)p.nblk * p.DC * 1024);
+    p.off_pmbx_b = o;
+    if (with_pm && p.DC <= 32) o = lvae_align256(o + (size_t)p.cpad * p.DC * 32);
     p.total = o;
     return p;
 }

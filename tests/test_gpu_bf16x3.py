@@ -74,6 +74,28 @@ def test_bf16x3_redo_and_skip_branches():
     np.testing.assert_allclose(lq.cpu().numpy(), ref, rtol=2e-4, atol=2e-3)
 
 
+def test_bf16x3_prod_marginals_on_the_matrix_pipe():
+    """prod-marginals under the opt-in path (D <= 32): the rank-3 polynomial per dimension as ONE bf16 MFMA per
+    tile (pair_pm_bx.hip), with the same redo mechanism as the VALU kernel: far samples underflow the fixed
+    reference and are redone by pair_pm_online_kernel; the other waves keep their fast-pass sums."""
+    from lvae import estimators as E
+    rng = np.random.default_rng(7)
+    for N_, M_, D in ((700, 1000, 32), (333, 90, 16), (2100, 4200, 20)):
+        mu = rng.standard_normal((N_, D)).astype(np.float32)
+        logvar = (0.3 * rng.standard_normal((N_, D)) - 2.0).astype(np.float32)
+        z = (mu[rng.integers(0, N_, M_)] + 0.4 * rng.standard_normal((M_, D))).astype(np.float32)
+        z[M_ // 10: M_ // 10 + 40] += 40.0          # far in every dimension -> redo
+        z[M_ // 2: M_ // 2 + 11, min(3, D - 1)] -= 25.0   # far in one dimension only
+        ref, refpm = onp.approximate_log_q_z(mu, logvar, z, method="all", prod_marginals=True, reduce_mean=False)
+        lq, lqpm = E.approximate_log_q_z(dev(mu), dev(logvar), dev(z), method="all", prod_marginals=True,
+                                         reduce_mean=False, path=BX)
+        np.testing.assert_allclose(lqpm.cpu().numpy(), refpm, rtol=1e-4, atol=2e-3, err_msg=str((N_, M_, D)))
+        np.testing.assert_allclose(lq.cpu().numpy(), ref, rtol=1e-4, atol=2e-3, err_msg=str((N_, M_, D)))
+        lq1, lqpm1 = E.approximate_log_q_z(dev(mu), dev(logvar), dev(z), method="all", prod_marginals=True,
+                                           reduce_mean=False)
+        assert float((lqpm - lqpm1).abs().max()) <= 2e-3
+
+
 @pytest.mark.parametrize("n,D", [(65536, 32), (32768, 64)])
 def test_bf16x3_matches_fp32_path_at_full_size(n, D):
     """C2 (N = M = 65,536, D = 32) and a D = 64 case: per-sample agreement with the fp32 MFMA path."""

@@ -10,14 +10,15 @@ def run(N, M, D, iters=3):
     mu = torch.randn(N, D, device="cuda", generator=g)
     logvar = 0.5 * torch.randn(N, D, device="cuda", generator=g) - 1.0
     z = (mu[:M] if M <= N else mu.repeat((M + N - 1) // N, 1)[:M]) + torch.randn(M, D, device="cuda", generator=g) * torch.exp(0.5 * logvar[:1])
-    E.log_qz_raw(mu, logvar, z, math.log(N), True)
+    path = int(os.environ.get("LVAE_PATH", "0"))        # 3: the experimental bf16x3 path (joint and prod-marginals)
+    E.log_qz_raw(mu, logvar, z, math.log(N), True, path=path)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
-        E.log_qz_raw(mu, logvar, z, math.log(N), True)
+        E.log_qz_raw(mu, logvar, z, math.log(N), True, path=path)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
-    print(f"N={N} M={M} D={D} joint+pm: {dt*1e3:.2f} ms  {N*M*D/dt:.3e} (i,j,d) terms/s", flush=True)
+    print(f"path={path} N={N} M={M} D={D} joint+pm: {dt*1e3:.2f} ms  {N*M*D/dt:.3e} (i,j,d) terms/s", flush=True)
 
 if __name__ == "__main__":
     for a in sys.argv[1:]:
