@@ -25,6 +25,8 @@ step "kernel trace of the secondary paths"
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_paths" -o p -- python3 $R/tools/bench_paths.py > "$OUT/paths.log" 2>&1 || exit 1
 step "kernel trace of prod-marginals (C2)"
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_pm" -o p -- python3 $R/tools/bench_pm.py 65536,65536,32 4096,4096,32 > "$OUT/pm.log" 2>&1 || exit 1
+step "kernel trace of prod-marginals (C2), experimental bf16x3 path"
+LVAE_PATH=3 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_pm_bx" -o p -- python3 $R/tools/bench_pm.py 65536,65536,32 > "$OUT/pm_bx.log" 2>&1 || exit 1
 step "kernel trace of the permutation test (C4)"
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_perm" -o p -- python3 $R/tools/bench_perm.py 262144,262144,32,100 > "$OUT/perm.log" 2>&1 || exit 1
 step "kernel trace of the split-bf16 comparison"
