@@ -44,7 +44,7 @@ typedef enum {
 #define LVAE_PATH_DIRECT 2     /* VALU direct form (z-mu)^2 p, no cancellation */
 #define LVAE_PATH_MFMA_BF16X3 3 /* EXPERIMENTAL, opt-in: the same expansion as three bf16 limbs per value (six
                                 * limb products, fp32 accumulate, fp32-equivalent accuracy); D <= 64 (with
-                                * prod-marginals: their polynomial too, D <= 32); never chosen by
+                                * prod-marginals: their polynomial too); never chosen by
                                 * LVAE_PATH_AUTO */
 
 const char* lvae_last_error(void);

@@ -1,4 +1,4 @@
-// EXPERIMENTAL, opt-in (LVAE_PATH_MFMA_BF16X3 with prod-marginals, D <= 32): the product-of-marginals sweep with
+// EXPERIMENTAL, opt-in (LVAE_PATH_MFMA_BF16X3 with prod-marginals, D <= 64): the product-of-marginals sweep with
 // its polynomial on the bf16 matrix pipe.
 //
 // For one dimension d the base-2 log-density of sample z_i under posterior j is a rank-3 product
@@ -98,7 +98,7 @@ template <int DCT>
 __global__ void __launch_bounds__(256, 2)
 pair_pm_bx_kernel(const uint4* __restrict__ aop, const uint4* __restrict__ bop, float2* __restrict__ partial_pm,
                   int* __restrict__ redo_flags, int64_t C, int64_t cpad, int64_t nblk, int64_t blk_per_split,
-                  int DC) {
+                  int DC, int d0) {        // this launch covers dimensions d0 .. d0 + DCT - 1 of the DC padded ones
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -106,11 +106,11 @@ pair_pm_bx_kernel(const uint4* __restrict__ aop, const uint4* __restrict__ bop, 
     const int64_t b0 = (int64_t)blockIdx.y * blk_per_split;
     int64_t b1 = b0 + blk_per_split;
     if (b1 > nblk) b1 = nblk;
-    const int64_t flag_idx = ((int64_t)blockIdx.y * (DC / 16)) * (cpad / 64) + col_base / 64;
+    const int64_t flag_idx = ((int64_t)blockIdx.y * (DC / 16) + d0 / 16) * (cpad / 64) + col_base / 64;
     if (b0 >= b1) {                          // empty split: zero sums, nothing to redo
         if (lane == 0) redo_flags[flag_idx] = 0;
         for (int d = 0; d < DCT; ++d)
-            partial_pm[((int64_t)blockIdx.y * DC + d) * cpad + col_base + lane] = make_float2(0.f, 0.f);
+            partial_pm[((int64_t)blockIdx.y * DC + d0 + d) * cpad + col_base + lane] = make_float2(0.f, 0.f);
         return;
     }
     constexpr int STAGE = DCT * 64;          // uint4 per stage: one 32-row block, all dimensions
@@ -121,7 +121,7 @@ pair_pm_bx_kernel(const uint4* __restrict__ aop, const uint4* __restrict__ bop, 
     const int nb = (int)(b1 - b0);
     // linear block counter over both passes: t -> block b0 + t % nb, stage t & 1
     auto dma = [&](int t) {
-        const uint4* g = aop + (b0 + t % nb) * (int64_t)STAGE + lane;
+        const uint4* g = aop + ((b0 + t % nb) * (int64_t)DC + d0) * 64 + lane;
         uint4* l = ring + (t & 1) * STAGE;
 #pragma unroll
         for (int q0 = 0; q0 < DCT; q0 += 4) {
@@ -139,7 +139,7 @@ pair_pm_bx_kernel(const uint4* __restrict__ aop, const uint4* __restrict__ bop, 
         const int64_t col = col_base + pass * 32 + r;
         pmbx_bf16x8 bz[DCT];
 #pragma unroll
-        for (int d = 0; d < DCT; ++d) bz[d] = __builtin_bit_cast(pmbx_bf16x8, bop[(col * DC + d) * 2 + h]);
+        for (int d = 0; d < DCT; ++d) bz[d] = __builtin_bit_cast(pmbx_bf16x8, bop[(col * DC + d0 + d) * 2 + h]);
         float S[DCT];
 #pragma unroll
         for (int d = 0; d < DCT; ++d) S[d] = 0.f;
@@ -172,7 +172,7 @@ pair_pm_bx_kernel(const uint4* __restrict__ aop, const uint4* __restrict__ bop, 
             float s = S[d];
             s += __shfl_xor(s, 32, 64);      // the two half-waves hold complementary posterior rows of the same sample
             ok = ok && s >= PMBX_SUM_MIN && s <= PMBX_SUM_MAX;
-            if (h == 0 && col < cpad) partial_pm[((int64_t)blockIdx.y * DC + d) * cpad + col] = make_float2(0.f, s);
+            if (h == 0 && col < cpad) partial_pm[((int64_t)blockIdx.y * DC + d0 + d) * cpad + col] = make_float2(0.f, s);
         }
     }
     // samples beyond C are padding (finite sums by construction); a flagged wave is redone for all its 64 samples
@@ -181,7 +181,7 @@ pair_pm_bx_kernel(const uint4* __restrict__ aop, const uint4* __restrict__ bop, 
 }
 
 // ---- host side -----------------------------------------------------------------------------------------
-bool lvae_pm_bx_supported(int DC) { return DC == 16 || DC == 32; }
+bool lvae_pm_bx_supported(int DC) { return DC == 16 || DC == 32 || DC == 64; }
 size_t lvae_pm_bx_a_bytes(int64_t nblk, int DC) { return (size_t)nblk * DC * 64 * sizeof(uint4); }
 size_t lvae_pm_bx_b_bytes(int64_t cpad, int DC) { return (size_t)cpad * DC * 2 * sizeof(uint4); }
 
@@ -199,12 +199,13 @@ int lvae_launch_pm_bx(const PairPlan& p, const float* z, const float* mu, const 
                        p.C, p.cpad, p.D, p.DC, hdr, inv, (uint4*)bop);
     const dim3 grid((unsigned)(p.cpad / 256), (unsigned)p.dsplit);
     const int64_t bps = p.rows_per_dsplit / 32;
-    if (p.DC == 32)
-        hipLaunchKernelGGL((pair_pm_bx_kernel<32>), grid, dim3(256), 0, st, (const uint4*)aop, (const uint4*)bop,
-                           partial_pm, redo_flags, p.C, p.cpad, p.nblk, bps, p.DC);
-    else
+    if (p.DC == 16)
         hipLaunchKernelGGL((pair_pm_bx_kernel<16>), grid, dim3(256), 0, st, (const uint4*)aop, (const uint4*)bop,
-                           partial_pm, redo_flags, p.C, p.cpad, p.nblk, bps, p.DC);
+                           partial_pm, redo_flags, p.C, p.cpad, p.nblk, bps, p.DC, 0);
+    else
+        for (int d0 = 0; d0 < p.DC; d0 += 32)        // per-dimension states are independent: 32 dimensions per launch
+            hipLaunchKernelGGL((pair_pm_bx_kernel<32>), grid, dim3(256), 0, st, (const uint4*)aop, (const uint4*)bop,
+                               partial_pm, redo_flags, p.C, p.cpad, p.nblk, bps, p.DC, d0);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }

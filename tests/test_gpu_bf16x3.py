@@ -75,12 +75,12 @@ def test_bf16x3_redo_and_skip_branches():
 
 
 def test_bf16x3_prod_marginals_on_the_matrix_pipe():
-    """prod-marginals under the opt-in path (D <= 32): the rank-3 polynomial per dimension as ONE bf16 MFMA per
+    """prod-marginals under the opt-in path (D <= 64): the rank-3 polynomial per dimension as ONE bf16 MFMA per
     tile (pair_pm_bx.hip), with the same redo mechanism as the VALU kernel: far samples underflow the fixed
     reference and are redone by pair_pm_online_kernel; the other waves keep their fast-pass sums."""
     from lvae import estimators as E
     rng = np.random.default_rng(7)
-    for N_, M_, D in ((700, 1000, 32), (333, 90, 16), (2100, 4200, 20)):
+    for N_, M_, D in ((700, 1000, 32), (333, 90, 16), (2100, 4200, 20), (600, 500, 64), (300, 400, 40)):
         mu = rng.standard_normal((N_, D)).astype(np.float32)
         logvar = (0.3 * rng.standard_normal((N_, D)) - 2.0).astype(np.float32)
         z = (mu[rng.integers(0, N_, M_)] + 0.4 * rng.standard_normal((M_, D))).astype(np.float32)
