@@ -841,7 +841,13 @@ extern "C" int lvae_mmd_workspace_bytes(int64_t n1, int64_t n2, int D, int64_t* 
 // Kernel-matrix sum over (kept = a [na], reduced = b [nb]) into *out (float64, device).
 static int ksum_epi(const KsumParams& kp) {
     if (!kp.poly) return 3;
-    return kp.n <= 1 ? 1 : (kp.n <= 16 ? 2 : 3);
+    if (kp.n <= 1) return 1;
+    if (kp.n > 16) return 3;
+    // coefficients in pairs (c0 = 0, c[2j+1] == c[2j+2]): the cheaper factored form, e.g. the reference's
+    // bandwidths 0, 0.1 .. 1.4 (loss_and_optimisation.py:598)
+    bool paired = kp.c[0] == 0.f;
+    for (int j = 0; j < 8 && paired; ++j) paired = kp.c[2 * j + 1] == kp.c[2 * j + 2];
+    return paired ? 5 : 2;
 }
 
 // Process-wide choice of the contraction behind the kernel-sum / MMD entry points (which have no `path`

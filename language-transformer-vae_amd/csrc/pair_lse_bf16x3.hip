@@ -135,6 +135,8 @@ static int launch_bx(const PairPlan& p, const float* rfrag, const float* rbias, 
         case 7: LVAE_PAIR(true, 3); break;
         case 8: LVAE_PAIR(false, 4); break;
         case 9: LVAE_PAIR(true, 4); break;
+        case 10: LVAE_PAIR(false, 5); break;
+        case 11: LVAE_PAIR(true, 5); break;
         default: return lvae_set_error(LVAE_ERR_INVALID, "bad epilogue id %d", epi);
     }
 #undef LVAE_PAIR
@@ -148,7 +150,7 @@ int lvae_launch_pair_bf16x3(const PairPlan& p, const float* rfrag, const float* 
                             float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
                             bool excl, int64_t excl_offset, int epi, const int* redo_flags, int sym,
                             const float* colnorm, hipStream_t st) {
-    if (epi >= 1 && epi <= 3 && !colnorm)
+    if (((epi >= 1 && epi <= 3) || epi == 5) && !colnorm)
         return lvae_set_error(LVAE_ERR_INVALID, "kernel-sum epilogues need the per-column norms");
     if (p.cpad % (4 * 32 * p.NCB) != 0)
         return lvae_set_error(LVAE_ERR_INVALID, "pair plan: cpad %lld not a multiple of the tile", (long long)p.cpad);
@@ -173,8 +175,12 @@ static int launch_bx_perm(const PairPlan& p, const float* rfrag, const float* rb
         hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 1, true, true>), grid, dim3(256), 0, st, rfrag,
                            rbias, cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr,
                            sym, colnorm);
-    else
+    else if (epi == 2)
         hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 2, true, true>), grid, dim3(256), 0, st, rfrag,
+                           rbias, cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr,
+                           sym, colnorm);
+    else
+        hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 5, true, true>), grid, dim3(256), 0, st, rfrag,
                            rbias, cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr,
                            sym, colnorm);
     LVAE_LAUNCH_CHECK();
@@ -188,7 +194,7 @@ int lvae_launch_pair_bf16x3_perm(const PairPlan& p, const float* rfrag, const fl
         return lvae_set_error(LVAE_ERR_INVALID, "symmetric permutation sums need col_offset %% 32 == 0");
     if (p.NCB != 1 || p.cpad % 128 != 0)
         return lvae_set_error(LVAE_ERR_INVALID, "permutation plan needs NCB == 1 and cpad %% 128 == 0");
-    if (epi != 1 && epi != 2)
+    if (epi != 1 && epi != 2 && epi != 5)
         return lvae_set_error(LVAE_ERR_UNSUPPORTED,
                               "the permutation test needs bandwidths that are integer multiples (<= 16) of the "
                               "smallest one");

@@ -62,9 +62,10 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 //        accumulated per column in float64 (one tile's 16 terms are first summed in float32).
 //        EPI 1: one bandwidth; EPI 2: alpha_k = base * (integer <= 16), f is a polynomial in
 //        t = exp(-base*v) evaluated by Horner's rule on the packed fp32 pipe (one v_exp_f32 per pair for
-//        any number of bandwidths); EPI 3: one exponential per bandwidth.
+//        any number of bandwidths; EPI 5: the same with paired coefficients, see KC below); EPI 3: one
+//        exponential per bandwidth.
 //        sym: a sample against itself -- only the tiles on and above the diagonal are visited.
-// PERM (with EPI 1/2, NCB == 1): label-permutation sums for the MMD permutation test.  Every 32x32
+// PERM (with EPI 1/2/5, NCB == 1): label-permutation sums for the MMD permutation test.  Every 32x32
 //        tile of kernel values K[r][c] is, straight from the accumulator layout, the A operand
 //        (i = column c, k = row r) of v_mfma_f32_32x32x16_bf16 against 0/1 label fragments
 //        L[r][p] (128 labelings, four 32-wide tiles), split into two bf16 limbs (hi + lo, ~17 bits):
@@ -83,7 +84,8 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
                      int64_t nblk, int64_t blk_per_split, int64_t cpad, int64_t excl_offset,
                      PermArgs pa, const int* __restrict__ redo_flags, int sym,
                      const float* __restrict__ colnorm) {
-    static_assert(!PERM || (NCB == 1 && (EPI == 1 || EPI == 2)), "PERM needs NCB == 1 and a polynomial epilogue");
+    static_assert(!PERM || (NCB == 1 && (EPI == 1 || EPI == 2 || EPI == 5)), "PERM needs NCB == 1 and a polynomial epilogue");
+    constexpr bool KS = EPI == 1 || EPI == 2 || EPI == 3 || EPI == 5;      // kernel-sum epilogues
     static_assert(!BX || DP <= 64, "the split-bf16 contraction is built for D <= 64");
     // Path gate: the conditioning estimate written by prep decides between this kernel and the direct
     // one without a host round trip (both are launched; the unselected one exits here).
@@ -145,7 +147,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     // sym (kernel sums of a sample against itself, totals only): the matrix is symmetric, so a column
     // block only visits the row blocks from its own diagonal tile on (weight 1) and counts the tiles
     // beyond it twice; the workgroup starts at its first column block's diagonal tile.
-    const bool use_sym = EPI >= 1 && EPI <= 3 && sym != 0;
+    const bool use_sym = KS && sym != 0;
     const int64_t sym_off = excl_offset / 32;    // block index of kept element 0 on the reduced axis (its diagonal)
     if (use_sym) {
         const int64_t gs = sym_off + (int64_t)blockIdx.x * 4 * NCB;
@@ -245,7 +247,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (want == 8 * g + e) c[4 * g + e] = (EPI >= 1 && EPI <= 3) ? INFINITY : -INFINITY;
+                    if (want == 8 * g + e) c[4 * g + e] = KS ? INFINITY : -INFINITY;
         }
     };
 
@@ -266,33 +268,43 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     // Kernel-sum parameters, read once into (scalar) registers: EPI 1 = one bandwidth (c0 + c1*t),
     // EPI 2 = polynomial of degree <= 16 in t, fully unrolled Horner (unused high coefficients are 0),
     // EPI 3 = arbitrary bandwidths, one exponential each.
-    constexpr int KC = EPI == 1 ? 2 : (EPI == 2 ? 17 : (EPI == 3 ? LVAE_KSUM_MAX : 1));
+    // EPI 5 = polynomial whose coefficients come in pairs (c0 = 0, c[2j+1] == c[2j+2] = e_j): t (1 + t) Q(t^2),
+    // ten packed operations instead of sixteen; the reference's fifteen bandwidths 0, 0.1 .. 1.4 are this case.
+    constexpr int KC = EPI == 1 ? 2 : (EPI == 2 ? 17 : (EPI == 3 ? LVAE_KSUM_MAX : (EPI == 5 ? 8 : 1)));
     float kc[KC];
     float k_eps = 0.f, k_nbase = 0.f;
     int k_n = 0;
-    if (EPI >= 1 && EPI <= 3) {
+    if (KS) {
         const KsumParams* kp = &hdr->ksum;
         k_eps = kp->eps;
         k_nbase = kp->nbase;
         k_n = kp->n;
 #pragma unroll
-        for (int k = 0; k < KC; ++k) kc[k] = kp->c[k];
+        for (int k = 0; k < KC; ++k) kc[k] = EPI == 5 ? kp->c[2 * k + 1] : kp->c[k];
     }
     // Kernel sums contract the LINEAR part of the squared distance only: the operands hold two dimensions per
     // fp32 MFMA step (POINT rows -2y against SAMPLE rows x; DP is the padded HALF dimension), the reduced
     // element's |y|^2 is the row bias and the kept element's |x|^2 (colnorm, one value per lane) is added here.
     float cn[NCB];
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) cn[cb] = (EPI >= 1 && EPI <= 3) ? colnorm[col0 + cb * 32 + r] : 0.f;
+    for (int cb = 0; cb < NCB; ++cb) cn[cb] = KS ? colnorm[col0 + cb * 32 + r] : 0.f;
     // two kernel values at a time (packed fp32 for the polynomial)
     auto kfun2 = [&](float d2a, float d2b, float cnv) -> f32x2 {
         const f32x2 v = {fabsf(d2a + cnv) + k_eps, fabsf(d2b + cnv) + k_eps};
-        if (EPI == 1 || EPI == 2) {
+        if (EPI == 1 || EPI == 2 || EPI == 5) {
             const f32x2 a = v * (f32x2){k_nbase, k_nbase};
             f32x2 t;
             t.x = lvae_exp2(a.x);
             t.y = lvae_exp2(a.y);
             if (EPI == 1) return __builtin_elementwise_fma((f32x2){kc[1], kc[1]}, t, (f32x2){kc[0], kc[0]});
+            if (EPI == 5) {
+                const f32x2 t2 = t * t;
+                const f32x2 lin = t2 + t;                 // t (1 + t)
+                f32x2 q = {kc[7], kc[7]};
+#pragma unroll
+                for (int k = 6; k >= 0; --k) q = __builtin_elementwise_fma(q, t2, (f32x2){kc[k], kc[k]});
+                return lin * q;
+            }
             f32x2 pacc = {kc[16], kc[16]};
 #pragma unroll
             for (int k = 15; k >= 0; --k) pacc = __builtin_elementwise_fma(pacc, t, (f32x2){kc[k], kc[k]});
@@ -486,7 +498,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
                 mask_bias(cvm[cb], cb, blk);
             }
         }
-        if (EPI >= 1 && EPI <= 3) set_weights(blk - 1);
+        if (KS) set_weights(blk - 1);
         if constexpr (BX) {
             const int stage = t_lin % NST;
             const int stage_next = (t_lin + 1) % NST;
@@ -608,7 +620,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
             run_block(accB, accA, blk, true);
             run_block(accA, accB, blk + 1, true);
         }
-        if (EPI >= 1 && EPI <= 3) set_weights(b1 - 1);
+        if (KS) set_weights(b1 - 1);
         if (blk < b1) {
             run_block(accB, accA, blk, true);
             set_weights(b1 - 1);

@@ -23,6 +23,8 @@ static int launch_t(const PairPlan& p, const float* rfrag, const float* rbias, c
         case 7: LVAE_PAIR(true, 3); break;
         case 8: LVAE_PAIR(false, 4); break;
         case 9: LVAE_PAIR(true, 4); break;
+        case 10: LVAE_PAIR(false, 5); break;
+        case 11: LVAE_PAIR(true, 5); break;
         default: return lvae_set_error(LVAE_ERR_INVALID, "bad epilogue id %d", epi);
     }
 #undef LVAE_PAIR
@@ -32,8 +34,8 @@ static int launch_t(const PairPlan& p, const float* rfrag, const float* rbias, c
 
 // cond_limit < 0: run unconditionally.  Otherwise run iff (cond > cond_limit) == use_if_above.
 // epi 0: logsumexp epilogue with a running maximum; 4: logsumexp against the fixed reference folded into
-// the row biases; 1/2/3: kernel-matrix column sums (float64 partials; parameters in hdr->ksum: single
-// bandwidth / polynomial of degree <= 16 / arbitrary bandwidths).
+// the row biases; 1/2/3/5: kernel-matrix column sums (float64 partials; parameters in hdr->ksum: single
+// bandwidth / polynomial of degree <= 16 / arbitrary bandwidths / polynomial with paired coefficients).
 // redo_flags (may be NULL): one int per workgroup column group; workgroups whose flag is 0 exit.
 // colnorm (epi 1/2/3 only, else NULL): |x_c|^2 per kept element, see the kernel.
 // sym != 0 (epi 1/2/3 only; the kept elements are rows excl_offset.. of the reduced sample, excl_offset a
@@ -46,7 +48,7 @@ int lvae_launch_pair_mfma(const PairPlan& p, const float* rfrag, const float* rb
     if (p.cpad % (4 * 32 * p.NCB) != 0)
         return lvae_set_error(LVAE_ERR_INVALID, "pair plan: cpad %lld not a multiple of the tile",
                               (long long)p.cpad);
-    if (epi >= 1 && epi <= 3 && !colnorm)
+    if (((epi >= 1 && epi <= 3) || epi == 5) && !colnorm)
         return lvae_set_error(LVAE_ERR_INVALID, "kernel-sum epilogues need the per-column norms");
     switch (p.DP) {
         case 16: return launch_t<16, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, colnorm, st);
@@ -67,7 +69,7 @@ int lvae_launch_pair_lse_mfma(const PairPlan& p, const float* rfrag, const float
 }
 
 // Kernel-matrix column sums plus label-permutation sums (see PERM above); diagonal pairs (reduced row ==
-// kept column + excl_offset) are always excluded.  The plan must have NCB == 1; epi 1 or 2.
+// kept column + excl_offset) are always excluded.  The plan must have NCB == 1; epi 1, 2 or 5.
 template <int DP, int WPS>
 static int launch_perm_t(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                          float2* partial, const PairHeader* hdr, int64_t excl_offset, int epi,
@@ -76,8 +78,11 @@ static int launch_perm_t(const PairPlan& p, const float* rfrag, const float* rbi
     if (epi == 1)
         hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 1, true>), grid, dim3(256), 0, st, rfrag, rbias,
                            cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr, sym, colnorm);
-    else
+    else if (epi == 2)
         hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 2, true>), grid, dim3(256), 0, st, rfrag, rbias,
+                           cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr, sym, colnorm);
+    else
+        hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 5, true>), grid, dim3(256), 0, st, rfrag, rbias,
                            cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr, sym, colnorm);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
@@ -90,7 +95,7 @@ int lvae_launch_pair_mfma_perm(const PairPlan& p, const float* rfrag, const floa
         return lvae_set_error(LVAE_ERR_INVALID, "symmetric permutation sums need col_offset %% 32 == 0");
     if (p.NCB != 1 || p.cpad % 128 != 0)
         return lvae_set_error(LVAE_ERR_INVALID, "permutation plan needs NCB == 1 and cpad %% 128 == 0");
-    if (epi != 1 && epi != 2)
+    if (epi != 1 && epi != 2 && epi != 5)
         return lvae_set_error(LVAE_ERR_UNSUPPORTED,
                               "the permutation test needs bandwidths that are integer multiples (<= 16) of the "
                               "smallest one");

@@ -190,6 +190,11 @@ def test_tts_mmd_unpinned(n1, n2, D):
     if n1 <= 300:
         got2, Kg = MMDStatistic(n1, n2)(dev(a), dev(b), alphas, ret_matrix=True)
         close(Kg, K, rtol=1e-4, atol=1e-5)
+    # multiples without the pairing take the general polynomial
+    al4 = [0.0, 0.1, 0.2, 0.3, 0.7, 1.1]
+    ref4 = onp.mmd_statistic_tts(a, b, al4)
+    got4 = float(MMDStatistic(n1, n2)(dev(a), dev(b), al4))
+    assert abs(got4 - ref4) <= 1e-4 * abs(ref4)
     # non-multiple bandwidths take the general (one exp per bandwidth) epilogue
     al2 = [0.05, 0.13, 0.31]
     ref2 = onp.mmd_statistic_tts(a, b, al2)
@@ -214,8 +219,11 @@ def test_kernel_sum_blocks(na, nb, D, off):
     if off >= 0 and na + off <= nb:
         b[off:off + na] = a                 # the excluded pairs are genuine self-pairs
     a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    # (paired-coefficient polynomial, one bandwidth, arbitrary bandwidths, zeros only, general polynomial,
+    #  paired polynomial with unequal pairs)
     for alphas, eps in (([0.1 * i for i in range(15)], 1e-5), ([1.0 / D ** 2], 0.0), ([0.0, 0.07, 0.19], 1e-5),
-                        ([0.0, 0.0], 0.0)):
+                        ([0.0, 0.0], 0.0), ([0.05, 0.1, 0.15, 0.25, 0.25, 0.8], 1e-5),
+                        ([0.03, 0.06, 0.09, 0.09, 0.12, 0.12, 0.45, 0.48], 1e-5)):
         d2 = eps + np.abs((a64 ** 2).sum(1)[:, None] + (b64 ** 2).sum(1)[None] - 2.0 * a64 @ b64.T)
         K = sum(np.exp(-al * d2) for al in alphas)
         for excl in (False, True):
@@ -257,7 +265,8 @@ def test_mmd_permutation_test_unpinned(n1, n2, D, P):
     scale = 1.0 if D <= 128 else 4.0 / np.sqrt(D)        # keep the kernel values away from underflow at wide D
     a = (rng.standard_normal((n1, D)) * scale).astype(np.float32)
     b = ((rng.standard_normal((n2, D)) * 0.9 + 0.15) * scale).astype(np.float32)
-    alphas = [0.1 * i for i in range(15)] if D != 64 else [0.02]
+    # (fifteen multiples: the paired-coefficient polynomial; D = 16: a general polynomial; D = 64: one bandwidth)
+    alphas = [0.1 * i for i in range(15)] if D not in (16, 64) else ([0.02] if D == 64 else [0.1, 0.2, 0.3, 0.5, 0.5, 0.9])
     ref_obs, K = onp.mmd_statistic_tts(a, b, alphas, ret_matrix=True)
     labels = E.permutation_labels(n1, n2, P, "cuda", torch.Generator(device="cuda").manual_seed(5))
     assert labels.shape == (P + 1, n1 + n2) and bool((labels.sum(1) == n1).all())
