@@ -65,4 +65,21 @@ if kt and cc:
                    "mfma_util_pct_by_cycles": 100.0 * busy / (cyc * 1024),
                    "mfma_instructions_per_launch": sum(r[1]["SQ_INSTS_MFMA"] for r in rows) / n},
                   open(os.path.join(dst, "pmc_bf16x3_pair_kernel.json"), "w"), indent=1)
+# the stats CSV averages ALL launches of the dominant kernel (clock-ramp and warm-up steps included); the timed
+# region of bench.py is the last `steps` of them: their average is what bench.py's roofline.kernel_ms_avg must match
+kt = first("trace_bench/**/*kernel_trace.csv")
+log = os.path.join(src, "trace_bench.log")
+if kt and os.path.exists(log):
+    line = next((l for l in open(log) if l.startswith('{"metric"')), None)
+    rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                  for r in csv.DictReader(open(kt)) if "pair_lse_mfma_kernel<32, 2, 2, false, 4, false, false>" in r["Kernel_Name"])
+    if line and rows:
+        b = json.loads(line)
+        k = int(b["steps"] * b["roofline"]["launches_per_step"])
+        json.dump({"kernel": "pair_lse_mfma_kernel<32,2,2,false,4>", "launches_in_trace": len(rows),
+                   "mean_ms_all_launches": sum(d for _, d in rows) / len(rows) / 1e6,
+                   "timed_region_launches": k, "mean_ms_timed_region": sum(d for _, d in rows[-k:]) / k / 1e6,
+                   "bench_py_kernel_ms_avg_same_run": b["roofline"]["kernel_ms_avg"],
+                   "bench_py_ms_per_step_same_run": b["ms_per_step"]},
+                  open(os.path.join(dst, "timed_region_bench_n1.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
