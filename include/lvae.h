@@ -39,13 +39,15 @@ typedef enum {
 #define LVAE_SPREAD_VAR 1      /* mutual_information.py: var / covariance diag  */
 
 /* which kernel family evaluates the pair matrix */
-#define LVAE_PATH_AUTO 0       /* MFMA unless the conditioning estimate says otherwise */
+#define LVAE_PATH_AUTO 0       /* fp32 MFMA unless the conditioning estimate says otherwise; the prod-marginals
+                                * sweep (D <= 64, from 2^22 pairs) then evaluates its per-dimension polynomial on
+                                * the bf16 matrix pipe (three limbs per value, fp32-equivalent), else on the VALU */
 #define LVAE_PATH_MFMA 1       /* fp32 MFMA quadratic expansion                */
 #define LVAE_PATH_DIRECT 2     /* VALU direct form (z-mu)^2 p, no cancellation */
 #define LVAE_PATH_MFMA_BF16X3 3 /* EXPERIMENTAL, opt-in: the same expansion as three bf16 limbs per value (six
                                 * limb products, fp32 accumulate, fp32-equivalent accuracy); D <= 64 (with
-                                * prod-marginals: their polynomial too); never chosen by
-                                * LVAE_PATH_AUTO */
+                                * prod-marginals: their polynomial too, ungated); the joint-density form is
+                                * never chosen by LVAE_PATH_AUTO */
 
 const char* lvae_last_error(void);
 int lvae_version(void);

@@ -27,11 +27,12 @@ int lvae_launch_pair_lse_mfma(const PairPlan& p, const float* rfrag, const float
 int lvae_launch_pair_direct(const PairPlan& p, bool joint, bool pm, const float* z,
                             const float* dparams, float2* partial, float2* partial_pm, int* redo_flags,
                             const PairHeader* hdr, float cond_limit, int use_if_above, int excl,
-                            int64_t excl_offset, hipStream_t st, bool pm_fast_done = false);
+                            int64_t excl_offset, hipStream_t st, bool pm_fast_done = false,
+                            float pm_cond_limit = -1.0f);
 bool lvae_pm_bx_supported(int DC);
 int lvae_launch_pm_bx(const PairPlan& p, const float* z, const float* mu, const float* spread, int spread_kind,
                       const PairHeader* hdr, void* aop, void* bop, float2* partial_pm, int* redo_flags,
-                      hipStream_t st);
+                      float cond_limit, hipStream_t st);
 
 int lvae_launch_reduce(int mode, const float* x, int64_t n, double scale, double* out, double* part,
                        hipStream_t st);
@@ -201,6 +202,9 @@ static hipEvent_t prof_mark(hipStream_t st, hipEvent_t open) {
 // weight in the logsumexp).  One fp32 ulp of that is the absolute error scale in nats:
 // 2^-23 * cond <= ~2.4e-3  <=>  cond <= 2e4.
 #define LVAE_COND_LIMIT 2.0e4f
+// Smallest N*M from which the AUTO path runs the prod-marginals polynomial on the bf16 matrix pipe (two more
+// operand-prep launches; measured faster from 2048 x 2048 up, launch-bound calls keep the single VALU sweep).
+#define LVAE_PM_BX_MIN_PAIRS 4194304.0
 
 static int check_ws(const void* ws, int64_t ws_bytes, size_t need) {
     if (!ws) return lvae_set_error(LVAE_ERR_WORKSPACE, "workspace pointer is NULL (need %zu bytes)", need);
@@ -330,16 +334,21 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     }
     if (need_direct) {
         const bool djoint = want_joint && joint_path != LVAE_PATH_MFMA;
-        // opt-in bf16x3 path: the prod-marginals polynomial runs on the bf16 matrix pipe too (D <= 32)
-        const bool pm_bx = bx && with_pm && p.DP && lvae_pm_bx_supported(p.DC);
-        if (pm_bx) {
+        // The prod-marginals polynomial on the bf16 matrix pipe (D <= 64; three bf16 limbs per value, fp32-equivalent):
+        // unconditionally on the opt-in bf16x3 path; in AUTO mode behind the same device-side conditioning test as
+        // the joint density (the packed-fp32 direct form runs with the opposite gate), from LVAE_PM_BX_MIN_PAIRS on.
+        const bool pm_bx_ok = with_pm && p.DP && lvae_pm_bx_supported(p.DC);
+        const bool pm_bx_forced = bx && pm_bx_ok;
+        const bool pm_bx_auto = !bx && pm_bx_ok && gated && need_mfma && (double)N * (double)M >= LVAE_PM_BX_MIN_PAIRS;
+        if (pm_bx_forced || pm_bx_auto) {
             rc = lvae_launch_pm_bx(p, z, mu, spread, spread_kind, hdr, base + p.off_pmbx_a, base + p.off_pmbx_b,
-                                   dpartial_pm, (int*)(base + p.off_dflags), st);
+                                   dpartial_pm, (int*)(base + p.off_dflags), pm_bx_auto ? LVAE_COND_LIMIT : -1.0f, st);
             if (rc) return rc;
         }
         rc = lvae_launch_pair_direct(p, djoint, with_pm, z, dparams, dpartial, dpartial_pm,
                                      (int*)(base + p.off_dflags), hdr, limit, 1,
-                                     exclude_diag, diag_offset, st, pm_bx);
+                                     exclude_diag, diag_offset, st, pm_bx_forced,
+                                     pm_bx_auto ? LVAE_COND_LIMIT : -1.0f);
         if (rc) return rc;
     }
     if (prof_stop) prof_mark(st, prof_stop);

@@ -77,7 +77,10 @@ template <int DCT>
 __global__ void __launch_bounds__(256)
 pair_pm_kernel(const float* __restrict__ z, const float* __restrict__ dparams,
                float2* __restrict__ partial_pm, int* __restrict__ redo_flags, int64_t C, int64_t cpad,
-               int64_t R, int64_t rows_per_split, int D, int DC, int d0) {
+               int64_t R, int64_t rows_per_split, int D, int DC, int d0,
+               const PairHeader* __restrict__ hdr, float cond_limit) {
+    // cond_limit >= 0: the matrix-pipe form (pair_pm_bx_kernel) covers well-conditioned inputs, this one the rest
+    if (cond_limit >= 0.f && !(__uint_as_float(hdr->cond_bits) > cond_limit)) return;
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = col < C ? col : C - 1;
     const int64_t j0 = (int64_t)blockIdx.y * rows_per_split;
@@ -245,23 +248,25 @@ static int launch_joint(const PairPlan& p, const float* z, const float* dparams,
 
 template <int DCT>
 static int launch_pm(const PairPlan& p, const float* z, const float* dparams, float2* partial_pm,
-                     int* redo_flags, int d0, hipStream_t st) {
+                     int* redo_flags, int d0, const PairHeader* hdr, float pm_cond_limit, hipStream_t st) {
     const dim3 grid((unsigned)(p.cpad / 256), (unsigned)p.dsplit);
     hipLaunchKernelGGL((pair_pm_kernel<DCT>), grid, dim3(256), 0, st, z, dparams, partial_pm, redo_flags,
-                       p.C, p.cpad, p.R, p.rows_per_dsplit, p.D, p.DC, d0);
+                       p.C, p.cpad, p.R, p.rows_per_dsplit, p.D, p.DC, d0, hdr, pm_cond_limit);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }
 
 // joint: produce the log q(z) partials (gated on the conditioning estimate when cond_limit >= 0);
-// pm: produce the product-of-marginals partials (never gated); pm_fast_done: the fast pass has been run by
-// lvae_launch_pm_bx (same partial layout, same flags), only the redo of flagged waves is launched here.
+// pm: produce the product-of-marginals partials; pm_fast_done: the fast pass has been run by
+// lvae_launch_pm_bx (same partial layout, same flags), only the redo of flagged waves is launched here;
+// pm_cond_limit >= 0: lvae_launch_pm_bx ran gated on the conditioning estimate, and the fast pass here runs
+// with the opposite gate (exactly one of the two writes the partials and the flags).
 // The direct parameters are padded (w = b = 0, a zero term) to DC columns: 16/32/64 for D <= 64, where
 // the kernels keep the whole latent row in registers, else a multiple of 16.
 int lvae_launch_pair_direct(const PairPlan& p, bool joint, bool pm, const float* z,
                             const float* dparams, float2* partial, float2* partial_pm, int* redo_flags,
                             const PairHeader* hdr, float cond_limit, int use_if_above, int excl,
-                            int64_t excl_offset, hipStream_t st, bool pm_fast_done) {
+                            int64_t excl_offset, hipStream_t st, bool pm_fast_done, float pm_cond_limit) {
     if (p.cpad % 256 != 0)
         return lvae_set_error(LVAE_ERR_INVALID, "pair plan: cpad %lld not a multiple of 256",
                               (long long)p.cpad);
@@ -284,8 +289,8 @@ int lvae_launch_pair_direct(const PairPlan& p, bool joint, bool pm, const float*
         // per-dimension states are independent: latent rows wider than 32 are swept in 32-wide chunks
         int zper = DC >= 32 ? 2 : 1;
         for (int d0 = 0; d0 < DC && !pm_fast_done; d0 += 32) {   // (pm_fast_done: another kernel wrote partials + flags)
-            if (DC - d0 >= 32) rc = launch_pm<32>(p, z, dparams, partial_pm, redo_flags, d0, st);
-            else rc = launch_pm<16>(p, z, dparams, partial_pm, redo_flags, d0, st);
+            if (DC - d0 >= 32) rc = launch_pm<32>(p, z, dparams, partial_pm, redo_flags, d0, hdr, pm_cond_limit, st);
+            else rc = launch_pm<16>(p, z, dparams, partial_pm, redo_flags, d0, hdr, pm_cond_limit, st);
             if (rc != LVAE_OK) return rc;
         }
         // DC % 32 == 16: the last fast launch covers one group, and its flag sits at that group's index,

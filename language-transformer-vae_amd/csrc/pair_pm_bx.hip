@@ -1,5 +1,6 @@
-// EXPERIMENTAL, opt-in (LVAE_PATH_MFMA_BF16X3 with prod-marginals, D <= 64): the product-of-marginals sweep with
-// its polynomial on the bf16 matrix pipe.
+// The product-of-marginals sweep with its polynomial on the bf16 matrix pipe (D <= 64): the fast pass of
+// LVAE_PATH_AUTO for well-conditioned inputs (device-side gate, like the joint density's) and of the opt-in
+// LVAE_PATH_MFMA_BF16X3 (there unconditionally).
 //
 // For one dimension d the base-2 log-density of sample z_i under posterior j is a rank-3 product
 //     t_ijd = A_jd z_id^2 + B_jd z_id + C_jd,   A = -w2, B = 2 mu w2, C = b - mu^2 w2,
@@ -12,8 +13,8 @@
 //   B operand (kept axis, per sample and dimension)         : k = [Zh Zm Zh Zl Zh Zm zh zm | zh zl zh zm 1  1  1  0]
 // (Z = z^2; lanes 0..31 hold k 0..7, lanes 32..63 k 8..15).  Same contract as pair_pm_kernel: fixed reference 0,
 // partials (0, sum) per (split, dimension, sample), one redo flag per (split, 64 samples); pair_pm_online_kernel
-// repeats flagged waves.  The expansion cancels like the joint one: conditioning is the caller's risk on this
-// forced path.
+// repeats flagged waves.  The expansion cancels like the joint one (each dimension's terms are bounded by the
+// joint conditioning estimate): gated on hdr->cond_bits when cond_limit >= 0, else the caller's risk.
 #include "pair_plan.h"
 
 typedef __bf16 pmbx_bf16x8 __attribute__((ext_vector_type(8)));
@@ -98,7 +99,10 @@ template <int DCT>
 __global__ void __launch_bounds__(256, 2)
 pair_pm_bx_kernel(const uint4* __restrict__ aop, const uint4* __restrict__ bop, float2* __restrict__ partial_pm,
                   int* __restrict__ redo_flags, int64_t C, int64_t cpad, int64_t nblk, int64_t blk_per_split,
-                  int DC, int d0) {        // this launch covers dimensions d0 .. d0 + DCT - 1 of the DC padded ones
+                  int DC, int d0,          // this launch covers dimensions d0 .. d0 + DCT - 1 of the DC padded ones
+                  const PairHeader* __restrict__ hdr, float cond_limit) {
+    // cond_limit >= 0 (AUTO path): run only for well-conditioned inputs; pair_pm_kernel carries the opposite gate
+    if (cond_limit >= 0.f && __uint_as_float(hdr->cond_bits) > cond_limit) return;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -188,7 +192,7 @@ size_t lvae_pm_bx_b_bytes(int64_t cpad, int DC) { return (size_t)cpad * DC * 2 *
 // aop / bop: workspace regions of lvae_pm_bx_a_bytes / lvae_pm_bx_b_bytes; hdr->colsum must be complete.
 int lvae_launch_pm_bx(const PairPlan& p, const float* z, const float* mu, const float* spread, int spread_kind,
                       const PairHeader* hdr, void* aop, void* bop, float2* partial_pm, int* redo_flags,
-                      hipStream_t st) {
+                      float cond_limit, hipStream_t st) {
     if (!lvae_pm_bx_supported(p.DC) || p.rows_per_dsplit % 32 != 0 || p.cpad % 256 != 0)
         return lvae_set_error(LVAE_ERR_INVALID, "prod-marginals bf16x3 kernel: unsupported plan (DC=%d)", p.DC);
     const double inv = 1.0 / (double)p.R;
@@ -201,11 +205,11 @@ int lvae_launch_pm_bx(const PairPlan& p, const float* z, const float* mu, const 
     const int64_t bps = p.rows_per_dsplit / 32;
     if (p.DC == 16)
         hipLaunchKernelGGL((pair_pm_bx_kernel<16>), grid, dim3(256), 0, st, (const uint4*)aop, (const uint4*)bop,
-                           partial_pm, redo_flags, p.C, p.cpad, p.nblk, bps, p.DC, 0);
+                           partial_pm, redo_flags, p.C, p.cpad, p.nblk, bps, p.DC, 0, hdr, cond_limit);
     else
         for (int d0 = 0; d0 < p.DC; d0 += 32)        // per-dimension states are independent: 32 dimensions per launch
             hipLaunchKernelGGL((pair_pm_bx_kernel<32>), grid, dim3(256), 0, st, (const uint4*)aop, (const uint4*)bop,
-                               partial_pm, redo_flags, p.C, p.cpad, p.nblk, bps, p.DC, d0);
+                               partial_pm, redo_flags, p.C, p.cpad, p.nblk, bps, p.DC, d0, hdr, cond_limit);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }

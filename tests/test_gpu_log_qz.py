@@ -102,6 +102,44 @@ def test_prod_marginals_redo_path():
     np.testing.assert_allclose(lqpm2.cpu().numpy(), refpm2, rtol=1e-4)
 
 
+@pytest.mark.parametrize("N,M,D", [(2100, 2100, 32), (2500, 1800, 64), (4096, 1100, 20)])
+def test_auto_path_prod_marginals_matrix_pipe_and_its_gate(N, M, D):
+    """From 2^22 pairs on the AUTO path runs the prod-marginals polynomial on the bf16 matrix pipe
+    (pair_pm_bx.hip, three limbs per value) behind the same device-side conditioning test as the joint density;
+    ill-conditioned inputs keep the direct packed-fp32 sweep.  Both against the oracle; the gate's choice is
+    read off bit-equality with the forced direct path."""
+    from lvae import estimators as E
+    from lvae import _native as N_
+    rng = np.random.default_rng(N + D)
+    mu = rng.standard_normal((N, D)).astype(np.float32)
+    logvar = (0.3 * rng.standard_normal((N, D)) - 2.0).astype(np.float32)
+    z = (mu[rng.integers(0, N, M)] + 0.4 * rng.standard_normal((M, D))).astype(np.float32)
+    z[M // 10: M // 10 + 40] += 40.0                     # far in every dimension -> redo by the running-max sweep
+    z[M // 2: M // 2 + 11, min(3, D - 1)] -= 25.0        # far in one dimension only
+    ref, refpm = onp.approximate_log_q_z(mu, logvar, z, method="all", prod_marginals=True, reduce_mean=False)
+    lq, lqpm = E.approximate_log_q_z(dev(mu), dev(logvar), dev(z), method="all", prod_marginals=True, reduce_mean=False)
+    lqd, lqpmd = E.approximate_log_q_z(dev(mu), dev(logvar), dev(z), method="all", prod_marginals=True,
+                                       reduce_mean=False, path=N_.PATH_DIRECT)
+    np.testing.assert_allclose(lqpm.cpu().numpy(), refpm, rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(lq.cpu().numpy(), ref, rtol=1e-4, atol=2e-3)
+    assert rel(lqpm.double().mean(), refpm.mean()) < 1e-5
+    assert float((lqpm - lqpmd).abs().max()) <= 2e-3
+    assert not torch.equal(lqpm, lqpmd)                  # a different kernel produced it
+    # peaked posteriors away from the origin: conditioning estimate above the limit -> the direct forms run
+    mu2 = (3.0 * rng.standard_normal((N, D))).astype(np.float32)
+    logvar2 = (0.2 * rng.standard_normal((N, D)) - 10.0).astype(np.float32)
+    z2 = (mu2[rng.integers(0, N, M)] + np.exp(-5.0) * rng.standard_normal((M, D))).astype(np.float32)
+    ref2, refpm2 = onp.approximate_log_q_z(mu2, logvar2, z2, method="all", prod_marginals=True, reduce_mean=False)
+    lq2, lqpm2 = E.approximate_log_q_z(dev(mu2), dev(logvar2), dev(z2), method="all", prod_marginals=True,
+                                       reduce_mean=False)
+    lq2d, lqpm2d = E.approximate_log_q_z(dev(mu2), dev(logvar2), dev(z2), method="all", prod_marginals=True,
+                                         reduce_mean=False, path=N_.PATH_DIRECT)
+    scale = max(1.0, float(np.abs(refpm2).max()))
+    np.testing.assert_allclose(lqpm2.cpu().numpy(), refpm2, rtol=1e-4, atol=1e-4 * scale)
+    np.testing.assert_allclose(lq2.cpu().numpy(), ref2, rtol=1e-4, atol=1e-4 * scale)
+    assert torch.equal(lqpm2, lqpm2d) and torch.equal(lq2, lq2d)
+
+
 def test_q1_raises():
     from lvae import estimators as E
     g = load_golden("logqz_generic")

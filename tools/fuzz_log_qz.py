@@ -11,17 +11,21 @@ from oracle import oracle_np as onp
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+big = len(sys.argv) > 3 and sys.argv[3] == "big"   # >= 2^22 pairs: the AUTO path's matrix-pipe prod-marginals sweep
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 bad = 0
 for c in range(cases):
     D = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 31, 32, 33, 48, 64, 65, 100, 128, 130]))
     Nn = int(rng.integers(1, 700))
     M = int(rng.integers(1, 700))
+    if big:
+        D = int(rng.choice([3, 16, 17, 32, 33, 48, 64]))
+        Nn, M = int(rng.integers(2048, 2700)), int(rng.integers(2048, 2700))
     mu = rng.standard_normal((Nn, D)).astype(np.float32) * rng.choice([0.1, 1.0, 3.0])
     lv = (rng.standard_normal((Nn, D)) * rng.choice([0.1, 0.5, 1.5]) + rng.choice([-3.0, -1.0, 0.0])).astype(np.float32)
     idx = rng.integers(0, Nn, M)
     z = (mu[idx] + rng.standard_normal((M, D)) * np.exp(0.5 * lv[idx]) * rng.choice([1.0, 3.0])).astype(np.float32)
-    pm = bool(rng.integers(0, 2))
+    pm = bool(rng.integers(0, 2)) or big
     ref, refpm = onp.approximate_log_q_z(mu, lv, z, method="all", prod_marginals=True, reduce_mean=False)
     for path in (0, 1, 2, 3):
         if path == 1 and D > 128: continue
