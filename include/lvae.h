@@ -40,7 +40,7 @@ typedef enum {
 
 /* which kernel family evaluates the pair matrix */
 #define LVAE_PATH_AUTO 0       /* fp32 MFMA unless the conditioning estimate says otherwise; the prod-marginals
-                                * sweep (D <= 64, from 2^22 pairs) then evaluates its per-dimension polynomial on
+                                * sweep (D <= 128, from 2^22 pairs) then evaluates its per-dimension polynomial on
                                 * the bf16 matrix pipe (three limbs per value, fp32-equivalent), else on the VALU */
 #define LVAE_PATH_MFMA 1       /* fp32 MFMA quadratic expansion                */
 #define LVAE_PATH_DIRECT 2     /* VALU direct form (z-mu)^2 p, no cancellation */

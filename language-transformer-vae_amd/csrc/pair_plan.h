@@ -147,9 +147,9 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
     o = lvae_align256(o + (size_t)(p.cpad / 128 + 1) * sizeof(int));
     // limb operands of the experimental bf16 prod-marginals kernel (pair_pm_bx.hip): 1 KiB per posterior / sample
     p.off_pmbx_a = o;
-    if (with_pm && p.DC <= 64) o = lvae_align256(o + (size_t)p.nblk * p.DC * 1024);
+    if (with_pm && p.DP != 0 && p.DC <= 128) o = lvae_align256(o + (size_t)p.nblk * p.DC * 1024);
     p.off_pmbx_b = o;
-    if (with_pm && p.DC <= 64) o = lvae_align256(o + (size_t)p.cpad * p.DC * 32);
+    if (with_pm && p.DP != 0 && p.DC <= 128) o = lvae_align256(o + (size_t)p.cpad * p.DC * 32);
     p.total = o;
     return p;
 }

@@ -1,4 +1,4 @@
-// The product-of-marginals sweep with its polynomial on the bf16 matrix pipe (D <= 64): the fast pass of
+// The product-of-marginals sweep with its polynomial on the bf16 matrix pipe (D <= 128): the fast pass of
 // LVAE_PATH_AUTO for well-conditioned inputs (device-side gate, like the joint density's) and of the opt-in
 // LVAE_PATH_MFMA_BF16X3 (there unconditionally).
 //
@@ -185,7 +185,7 @@ pair_pm_bx_kernel(const uint4* __restrict__ aop, const uint4* __restrict__ bop, 
 }
 
 // ---- host side -----------------------------------------------------------------------------------------
-bool lvae_pm_bx_supported(int DC) { return DC == 16 || DC == 32 || DC == 64; }
+bool lvae_pm_bx_supported(int DC) { return DC >= 16 && DC <= 128 && DC % 16 == 0; }
 size_t lvae_pm_bx_a_bytes(int64_t nblk, int DC) { return (size_t)nblk * DC * 64 * sizeof(uint4); }
 size_t lvae_pm_bx_b_bytes(int64_t cpad, int DC) { return (size_t)cpad * DC * 2 * sizeof(uint4); }
 
@@ -203,13 +203,14 @@ int lvae_launch_pm_bx(const PairPlan& p, const float* z, const float* mu, const 
                        p.C, p.cpad, p.D, p.DC, hdr, inv, (uint4*)bop);
     const dim3 grid((unsigned)(p.cpad / 256), (unsigned)p.dsplit);
     const int64_t bps = p.rows_per_dsplit / 32;
-    if (p.DC == 16)
-        hipLaunchKernelGGL((pair_pm_bx_kernel<16>), grid, dim3(256), 0, st, (const uint4*)aop, (const uint4*)bop,
-                           partial_pm, redo_flags, p.C, p.cpad, p.nblk, bps, p.DC, 0, hdr, cond_limit);
-    else
-        for (int d0 = 0; d0 < p.DC; d0 += 32)        // per-dimension states are independent: 32 dimensions per launch
+    for (int d0 = 0; d0 < p.DC; d0 += 32) {          // per-dimension states are independent: 32 dimensions per launch
+        if (p.DC - d0 >= 32)
             hipLaunchKernelGGL((pair_pm_bx_kernel<32>), grid, dim3(256), 0, st, (const uint4*)aop, (const uint4*)bop,
                                partial_pm, redo_flags, p.C, p.cpad, p.nblk, bps, p.DC, d0, hdr, cond_limit);
+        else                                         // (a 16-wide tail: its flag group index d0 / 16 is even, as
+            hipLaunchKernelGGL((pair_pm_bx_kernel<16>), grid, dim3(256), 0, st, (const uint4*)aop, (const uint4*)bop,
+                               partial_pm, redo_flags, p.C, p.cpad, p.nblk, bps, p.DC, d0, hdr, cond_limit);   // pair_pm_online_kernel expects)
+    }
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }

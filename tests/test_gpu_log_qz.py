@@ -102,7 +102,8 @@ def test_prod_marginals_redo_path():
     np.testing.assert_allclose(lqpm2.cpu().numpy(), refpm2, rtol=1e-4)
 
 
-@pytest.mark.parametrize("N,M,D", [(2100, 2100, 32), (2500, 1800, 64), (4096, 1100, 20)])
+@pytest.mark.parametrize("N,M,D", [(2100, 2100, 32), (2500, 1800, 64), (4096, 1100, 20), (2200, 2000, 100),
+                                    (2048, 2048, 128)])
 def test_auto_path_prod_marginals_matrix_pipe_and_its_gate(N, M, D):
     """From 2^22 pairs on the AUTO path runs the prod-marginals polynomial on the bf16 matrix pipe
     (pair_pm_bx.hip, three limbs per value) behind the same device-side conditioning test as the joint density;
