@@ -286,7 +286,8 @@ int lvae_categorical_bounds_f32(const float* probs, const int64_t* samples, int6
  * scipy.stats.ks_2samp(a, b) (two-sided) as called on the importance-weighted log-likelihood vectors at
  * utils_train.py:496-497 (scipy is a third-party dependency of the reference; 1.15.3 in this image).
  * out: 3 float64 in device memory: D = max(D+, D-), D+ = max_v(F_a(v) - F_b(v)), D- = max_v(F_b(v) - F_a(v))
- * clipped to [0, 1].  Inputs must not contain NaN.  n1, n2 >= 1, n1 + n2 <= 2^30. */
+ * clipped to [0, 1].  A NaN in either input makes all three NaN (scipy's nan_policy="propagate").
+ * n1, n2 >= 1, n1 + n2 <= 2^30. */
 int lvae_ks_2samp_workspace_bytes(int64_t n1, int64_t n2, int64_t* out_bytes);
 int lvae_ks_2samp_f32(const float* a, int64_t n1, const float* b, int64_t n2, double* out, void* ws,
                       int64_t ws_bytes, void* stream);

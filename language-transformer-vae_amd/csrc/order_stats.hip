@@ -15,9 +15,16 @@
 #define KS_THREADS 256
 
 __global__ void __launch_bounds__(256)
-ks_pad_copy_kernel(const float* __restrict__ src, int64_t n, int64_t npad, float* __restrict__ dst) {
+ks_pad_copy_kernel(const float* __restrict__ src, int64_t n, int64_t npad, float* __restrict__ dst,
+                   int* __restrict__ nan_flag) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < npad) dst[i] = i < n ? src[i] : INFINITY;
+    if (i >= npad) return;
+    float v = i < n ? src[i] : INFINITY;
+    if (v != v) {                 // a NaN has no place in the order: flag it (the statistic becomes NaN, as in
+        *nan_flag = 1;            // scipy) and keep the network's comparisons total
+        v = INFINITY;
+    }
+    dst[i] = v;
 }
 
 __device__ __forceinline__ void ks_cmpswap(float& a, float& b, bool ascending) {
@@ -96,7 +103,8 @@ ks_cdf_diff_kernel(const float* __restrict__ sa, int64_t n1, const float* __rest
 }
 
 __global__ void __launch_bounds__(256)
-ks_finalize_kernel(const double* __restrict__ block_ext, int64_t nblocks, double* __restrict__ out) {
+ks_finalize_kernel(const double* __restrict__ block_ext, int64_t nblocks, const int* __restrict__ nan_flag,
+                   double* __restrict__ out) {
     double dmax = -2.0, dmin = 2.0;
     for (int64_t b = threadIdx.x; b < nblocks; b += 256) {
         dmax = fmax(dmax, block_ext[2 * b]);
@@ -114,9 +122,10 @@ ks_finalize_kernel(const double* __restrict__ block_ext, int64_t nblocks, double
         const double mx = fmax(fmax(smx[0], smx[1]), fmax(smx[2], smx[3]));
         const double mn = fmin(fmin(smn[0], smn[1]), fmin(smn[2], smn[3]));
         const double min_s = fmin(fmax(-mn, 0.0), 1.0);
-        out[0] = fmax(min_s, mx);
-        out[1] = mx;                               // D+  (max of F_a - F_b)
-        out[2] = min_s;                            // D-
+        const bool bad = *nan_flag != 0;
+        out[0] = bad ? (double)NAN : fmax(min_s, mx);
+        out[1] = bad ? (double)NAN : mx;           // D+  (max of F_a - F_b)
+        out[2] = bad ? (double)NAN : min_s;        // D-
     }
 }
 
@@ -130,13 +139,14 @@ int64_t lvae_ks_padded(int64_t n) {
 size_t lvae_ks_workspace(int64_t n1, int64_t n2) {
     const int64_t blocks = lvae_ceil_div(n1 + n2, 256);
     return lvae_align256((size_t)lvae_ks_padded(n1) * sizeof(float)) +
-           lvae_align256((size_t)lvae_ks_padded(n2) * sizeof(float)) + lvae_align256((size_t)blocks * 2 * sizeof(double));
+           lvae_align256((size_t)lvae_ks_padded(n2) * sizeof(float)) + lvae_align256((size_t)blocks * 2 * sizeof(double)) +
+           256;                   // (+ the NaN flag)
 }
 
-static int ks_sort(const float* src, int64_t n, float* buf, hipStream_t st) {
+static int ks_sort(const float* src, int64_t n, float* buf, int* nan_flag, hipStream_t st) {
     const int64_t npad = lvae_ks_padded(n);
     hipLaunchKernelGGL(ks_pad_copy_kernel, dim3((unsigned)lvae_ceil_div(npad, 256)), dim3(256), 0, st, src, n, npad,
-                       buf);
+                       buf, nan_flag);
     const unsigned tiles = (unsigned)(npad / KS_TILE);
     hipLaunchKernelGGL(ks_bitonic_tile_kernel, dim3(tiles), dim3(KS_THREADS), 0, st, buf, (int64_t)2,
                        (int64_t)KS_TILE);
@@ -156,13 +166,15 @@ int lvae_launch_ks_2samp(const float* a, int64_t n1, const float* b, int64_t n2,
     float* sa = (float*)base;
     float* sb = (float*)(base + lvae_align256((size_t)lvae_ks_padded(n1) * sizeof(float)));
     double* ext = (double*)((char*)sb + lvae_align256((size_t)lvae_ks_padded(n2) * sizeof(float)));
-    int rc = ks_sort(a, n1, sa, st);
-    if (rc) return rc;
-    rc = ks_sort(b, n2, sb, st);
-    if (rc) return rc;
     const int64_t blocks = lvae_ceil_div(n1 + n2, 256);
+    int* nan_flag = (int*)((char*)ext + lvae_align256((size_t)blocks * 2 * sizeof(double)));
+    LVAE_HIP(hipMemsetAsync(nan_flag, 0, sizeof(int), st));
+    int rc = ks_sort(a, n1, sa, nan_flag, st);
+    if (rc) return rc;
+    rc = ks_sort(b, n2, sb, nan_flag, st);
+    if (rc) return rc;
     hipLaunchKernelGGL(ks_cdf_diff_kernel, dim3((unsigned)blocks), dim3(256), 0, st, sa, n1, sb, n2, ext);
-    hipLaunchKernelGGL(ks_finalize_kernel, dim3(1), dim3(256), 0, st, ext, blocks, out);
+    hipLaunchKernelGGL(ks_finalize_kernel, dim3(1), dim3(256), 0, st, ext, blocks, nan_flag, out);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }

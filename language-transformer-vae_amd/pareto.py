@@ -28,6 +28,8 @@ def ks_2samp(data1, data2):
         N.check(N.lib().lvae_ks_2samp_f32(N.ptr(a), n1, N.ptr(b), n2, N.ptr(out), N.ptr(ws), nbytes.value,
                                           N.stream_ptr(dev)))
     d = float(out[0])
+    if math.isnan(d):                 # a NaN in either sample: (nan, nan), as scipy's nan_policy="propagate"
+        return d, d
     lam = math.sqrt(n1 * n2 / (n1 + n2)) * d
     if lam < 1e-3:
         p = 1.0

@@ -69,6 +69,11 @@ def test_ks_statistic_bit_exact(n1, n2, shift, ties):
     if min(n1, n2) >= 1000:                                   # the limiting form is only close for large samples
         assert abs(p - ref.pvalue) < 0.02
     assert ks_2samp(a, a)[0] == 0.0                           # host arrays are accepted too (moved to the GPU)
+    if n1 >= 50:                                              # a NaN propagates, like scipy's default nan_policy
+        bad = a.copy()
+        bad[n1 // 3] = np.nan
+        assert all(np.isnan(v) for v in ks_2samp(bad, b)) and all(np.isnan(v) for v in ks_2samp(b, bad))
+        assert ks_2samp(a, b)[0] == d                         # (the flag does not outlive the call)
 
 
 def test_determine_pareto_checkpoint():
