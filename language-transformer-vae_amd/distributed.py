@@ -156,7 +156,8 @@ def overlapped_stats(packed_local, z_local, mu_local, logvar_local, group, log_n
 def sharded_latent_stats(mu_local, logvar_local, z_local, method="all", dataset_size=None,
                          prod_marginals=False, group=None, local_stats=hip_local_stats, counts=None,
                          overlap=None, block_kernels=HipBlockKernels):
-    """Marginal KL / MI (/ TC, dimension-wise KL) over posteriors and samples sharded by rows.
+    """Marginal KL / MI (/ TC, dimension-wise KL) over posteriors and samples sharded by rows: the device
+    part (``sharded_latent_sums``) followed by one host read of the five global sums (``stats_from_sums``).
 
     mu_local, logvar_local, z_local: this rank's [n_r, D] rows (z_i drawn from posterior i).
     Returns a dict of Python floats identical on every rank, with the definitions of
@@ -166,6 +167,32 @@ def sharded_latent_stats(mu_local, logvar_local, z_local, method="all", dataset_
     known (skips the size exchange).  ``overlap`` (default: whenever it applies -- the HIP path, equal
     shard sizes known through ``counts``, no prod-marginals, more than one rank): hide the all-gather behind
     the local block of the pair matrix, see ``overlapped_stats``."""
+    sums, log_q_z, n_total = sharded_latent_sums(mu_local, logvar_local, z_local, method, dataset_size, prod_marginals,
+                                                 group, local_stats, counts, overlap, block_kernels)
+    return stats_from_sums(sums, n_total, log_q_z, prod_marginals)
+
+
+def stats_from_sums(sums, n_total, log_q_z_local, prod_marginals=False):
+    """The estimates of loss_and_optimisation.py:816-824 from the five global float64 sums (reads them to the host)."""
+    s_lq, s_pm, s_lp, s_lqx, cnt = sums.tolist()
+    out = {
+        "n_total": int(n_total), "m_total": int(round(cnt)),
+        "log_q_z": s_lq / cnt, "log_p_z": s_lp / cnt, "log_q_z_x": s_lqx / cnt,
+        "marginal_kl": (s_lq - s_lp) / cnt, "mi": (s_lqx - s_lq) / cnt,
+        "log_q_z_local": log_q_z_local,
+    }
+    if prod_marginals:
+        out.update(log_q_z_prod_marg=s_pm / cnt, tc=(s_lq - s_pm) / cnt, dim_kl=(s_pm - s_lp) / cnt)
+    return out
+
+
+def sharded_latent_sums(mu_local, logvar_local, z_local, method="all", dataset_size=None,
+                        prod_marginals=False, group=None, local_stats=hip_local_stats, counts=None,
+                        overlap=None, block_kernels=HipBlockKernels):
+    """Exchange + per-rank compute + all-reduce of ``sharded_latent_stats`` without its host read: returns
+    (sums [5] float64 on the compute device, identical on every rank: sum log q(z), sum log prod-marginals,
+    sum log p(z), sum log q(z|x), row count; this rank's log q(z) vector; n_total).  Nothing here waits on
+    the host, so consecutive calls queue behind each other on the device."""
     packed = torch.cat([mu_local, logvar_local], dim=1).contiguous()
     if method == "chen":
         assert dataset_size is not None
@@ -194,16 +221,7 @@ def sharded_latent_stats(mu_local, logvar_local, z_local, method="all", dataset_
                                     prod_marginals)
     sums = sums.to(torch.float64).contiguous()
     _all_reduce(sums, dist.ReduceOp.SUM, group)
-    s_lq, s_pm, s_lp, s_lqx, cnt = sums.tolist()
-    out = {
-        "n_total": int(n_total), "m_total": int(round(cnt)),
-        "log_q_z": s_lq / cnt, "log_p_z": s_lp / cnt, "log_q_z_x": s_lqx / cnt,
-        "marginal_kl": (s_lq - s_lp) / cnt, "mi": (s_lqx - s_lq) / cnt,
-        "log_q_z_local": log_q_z,
-    }
-    if prod_marginals:
-        out.update(log_q_z_prod_marg=s_pm / cnt, tc=(s_lq - s_pm) / cnt, dim_kl=(s_pm - s_lp) / cnt)
-    return out
+    return sums, log_q_z, n_total
 
 
 def sharded_iw_log_p_x(mu_local, logvar_local, eps_local, log_p_x_z_local, group=None, gather=True):
