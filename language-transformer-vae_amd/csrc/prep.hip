@@ -18,7 +18,7 @@
 // Per-dimension sum of the posterior means.  Each block sweeps a contiguous slab of rows with fully
 // coalesced loads; a thread's dimension is fixed when 256 % D == 0 (register accumulation), otherwise
 // the slab is accumulated through LDS atomics.
-#define COLSUM_ROWS 128
+#define COLSUM_ROWS 512       // rows per workgroup: few enough workgroups that the float64 atomics on the D sums stay short
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ mu, int64_t n, int D,
                                                      PairHeader* hdr) {
     __shared__ float sm[256];
@@ -26,7 +26,31 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ m
     int64_t r1 = r0 + COLSUM_ROWS;
     if (r1 > n) r1 = n;
     const int64_t e0 = r0 * D, e1 = r1 * D;
-    if (D <= 256 && 256 % D == 0) {
+    if (D >= 4 && D <= 256 && 256 % D == 0) {
+        // 16-byte loads, four in flight; thread t always sees columns (4t .. 4t+3) % D (1024 % D == 0)
+        const float4* __restrict__ m4 = reinterpret_cast<const float4*>(mu);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int64_t q0 = e0 / 4, q1 = e1 / 4;
+        int64_t i = q0 + threadIdx.x;
+        for (; i + 768 < q1; i += 1024) {
+            const float4 a = m4[i], b = m4[i + 256], c = m4[i + 512], d = m4[i + 768];
+            acc.x += (a.x + b.x) + (c.x + d.x); acc.y += (a.y + b.y) + (c.y + d.y);
+            acc.z += (a.z + b.z) + (c.z + d.z); acc.w += (a.w + b.w) + (c.w + d.w);
+        }
+        for (; i < q1; i += 256) {
+            const float4 a = m4[i];
+            acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+        }
+        __shared__ float sm4[1024];
+        sm4[4 * threadIdx.x] = acc.x; sm4[4 * threadIdx.x + 1] = acc.y;
+        sm4[4 * threadIdx.x + 2] = acc.z; sm4[4 * threadIdx.x + 3] = acc.w;
+        __syncthreads();
+        if (threadIdx.x < D) {
+            double t = 0.0;
+            for (int k = threadIdx.x; k < 1024; k += D) t += (double)sm4[k];
+            atomicAdd(&hdr->colsum[threadIdx.x], t);
+        }
+    } else if (D <= 256 && 256 % D == 0) {
         float acc = 0.f;
         for (int64_t i = e0 + threadIdx.x; i < e1; i += 256) acc += mu[i];
         sm[threadIdx.x] = acc;
