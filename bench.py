@@ -117,13 +117,15 @@ def main():
     def step():
         if world > 1:
             state["dev"] = LD.sharded_latent_sums(mu, logvar, z, method="all", counts=[n_total // world] * world,
-                                                  overlap=exchange["overlap"])
+                                                  overlap=exchange["overlap"], async_reduce=True)
         else:
             sums, lq = LD.hip_local_stats(mu, logvar, z, mu, logvar, log_norm, False)
-            state["dev"] = (sums, lq, n_total)
+            state["dev"] = (sums, lq, n_total, None)
 
     def read_out():
-        sums, lq, n = state["dev"]
+        sums, lq, n, work = state["dev"]
+        if work is not None:
+            work.wait()
         state["out"] = LD.stats_from_sums(sums, n, lq)
 
     def fence():

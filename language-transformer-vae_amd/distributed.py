@@ -43,13 +43,15 @@ def _all_gather_into(out, x, group):
         dist.all_gather_into_tensor(out, x, group=group)
 
 
-def _all_reduce(x, op, group):
+def _all_reduce(x, op, group, async_op=False):
+    """In-place all-reduce; with ``async_op`` returns the work handle (or None where the collective has
+    already completed) and the current stream does NOT wait for the collective."""
     if x.is_cuda and _host_staged(group):
         tmp = x.cpu()
         dist.all_reduce(tmp, op=op, group=group)
         x.copy_(tmp)
-    else:
-        dist.all_reduce(x, op=op, group=group)
+        return None
+    return dist.all_reduce(x, op=op, group=group, async_op=async_op)
 
 
 def all_gather_rows(x, group=None, counts=None):
@@ -188,11 +190,13 @@ def stats_from_sums(sums, n_total, log_q_z_local, prod_marginals=False):
 
 def sharded_latent_sums(mu_local, logvar_local, z_local, method="all", dataset_size=None,
                         prod_marginals=False, group=None, local_stats=hip_local_stats, counts=None,
-                        overlap=None, block_kernels=HipBlockKernels):
+                        overlap=None, block_kernels=HipBlockKernels, async_reduce=False):
     """Exchange + per-rank compute + all-reduce of ``sharded_latent_stats`` without its host read: returns
     (sums [5] float64 on the compute device, identical on every rank: sum log q(z), sum log prod-marginals,
     sum log p(z), sum log q(z|x), row count; this rank's log q(z) vector; n_total).  Nothing here waits on
-    the host, so consecutive calls queue behind each other on the device."""
+    the host, so consecutive calls queue behind each other on the device.  ``async_reduce``: the compute
+    stream does not wait for the final all-reduce either (the next call's kernels start at once); a fourth
+    return value is then the collective's work handle (or None), to be ``wait()``-ed before ``sums`` is read."""
     packed = torch.cat([mu_local, logvar_local], dim=1).contiguous()
     if method == "chen":
         assert dataset_size is not None
@@ -220,7 +224,9 @@ def sharded_latent_sums(mu_local, logvar_local, z_local, method="all", dataset_s
         sums, log_q_z = local_stats(mu_all, logvar_all, z_local, mu_local, logvar_local, log_norm_of(n_total),
                                     prod_marginals)
     sums = sums.to(torch.float64).contiguous()
-    _all_reduce(sums, dist.ReduceOp.SUM, group)
+    work = _all_reduce(sums, dist.ReduceOp.SUM, group, async_op=async_reduce)
+    if async_reduce:
+        return sums, log_q_z, n_total, work
     return sums, log_q_z, n_total
 
 

@@ -294,6 +294,14 @@ def _overlap_worker(rank, world, port, n, D, q):
                                    block_kernels=_OracleBlockKernels)
     auto = LD.sharded_latent_stats(t(mu), t(lv), t(z), method="chen", dataset_size=500, counts=counts,
                                    block_kernels=_OracleBlockKernels)                 # overlap chosen by default
+    # the device-side half on its own, three calls queued before anything is read (bench.py's step): the
+    # all-reduce of each call is asynchronous and only the last one's handle is waited for
+    pending = [LD.sharded_latent_sums(t(mu), t(lv), t(z), method="all", counts=counts, overlap=True,
+                                      block_kernels=_OracleBlockKernels, async_reduce=True) for _ in range(3)]
+    sums, lq, n_tot, work = pending[-1]
+    if work is not None:
+        work.wait()
+    queued = LD.stats_from_sums(sums, n_tot, lq)
     err = None
     try:
         LD.sharded_latent_stats(t(mu), t(lv), t(z), prod_marginals=True, counts=counts, overlap=True,
@@ -303,6 +311,7 @@ def _overlap_worker(rank, world, port, n, D, q):
     if rank == 0:
         q.put({"plain": {k: v for k, v in plain.items() if isinstance(v, float)},
                "over": {k: v for k, v in over.items() if isinstance(v, float)},
+               "queued": {k: v for k, v in queued.items() if isinstance(v, float)},
                "auto_marginal_kl": auto["marginal_kl"], "lq_plain": plain["log_q_z_local"].numpy(),
                "lq_over": over["log_q_z_local"].numpy(), "err": err})
     dist.barrier()
@@ -326,6 +335,7 @@ def test_overlapped_exchange_matches_plain(world):
         assert p.exitcode == 0
     for k, v in res["plain"].items():
         assert abs(res["over"][k] - v) <= 1e-9 * max(1.0, abs(v)), k
+        assert res["queued"][k] == res["over"][k], k
     np.testing.assert_allclose(res["lq_over"], res["lq_plain"], rtol=1e-10, atol=1e-10)
     assert abs(res["auto_marginal_kl"] - (res["plain"]["marginal_kl"] - math.log(500))) < 1e-9
     assert res["err"] and "overlap=True needs" in res["err"]
