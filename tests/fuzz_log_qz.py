@@ -1,5 +1,7 @@
 """Randomised shape sweep of lvae_log_qz_f32 (all paths, with / without prod-marginals and diagonal exclusion)
-and the kernel sums against the NumPy oracle.  A development aid: prints every failing case."""
+and the kernel sums against the NumPy oracle.  Test infrastructure (it imports the oracle, so it lives under
+tests/), run by name on the GPU box -- `python tests/fuzz_log_qz.py <seed> <cases> [big]` -- and not collected by
+pytest; prints every failing case."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
