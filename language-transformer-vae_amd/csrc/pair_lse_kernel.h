@@ -226,12 +226,13 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
             }
         }
     };
-    // chunk index t (counted from this workgroup's first block) -> (block, chunk-in-block), clamped to
-    // the last chunk of the range so that running ahead past the end is a harmless re-read
-    const int t_end = (int)(b1 - b0) * CPB;              // < 2^31: a split holds at most 2^26 blocks
+    // chunk index t (counted from this workgroup's first block) -> (block, chunk-in-block); the block is clamped
+    // to the last one of the range, so that running ahead past the end is a harmless re-read -- into the stage and
+    // with the DMA count of the regular pattern, so the counted waits stay exact
     auto dma_linear = [&](int t) {
-        if (t >= t_end) t = t_end - 1;
-        dma_chunk(b0 + t / CPB, t % CPB, t % NST);
+        int64_t blk = b0 + t / CPB;
+        if (blk > b1 - 1) blk = b1 - 1;
+        dma_chunk(blk, t % CPB, t % NST);
     };
 
     // EXCL: drop the pair (reduced row == kept column + offset).  The row biases enter a tile as the C operand
@@ -425,7 +426,9 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     // wv: weight of the tile (sym: 0 below the diagonal tile -> nothing to do, 1 on it, 2 beyond; else 1).
     // A flush never mixes weights: the diagonal tile is flushed on its own.
     auto perm_tile = [&](int lstage, float wv) __attribute__((always_inline)) {
-        if (wv == 0.f) return;
+        // (a scalar branch, not a test of the per-lane copy of the weight: MFMA ignores EXEC, and the compiler may lower a
+        //  short conditional block to EXEC masking without a jump)
+        if (__builtin_amdgcn_readfirstlane(__float_as_int(wv)) == 0) return;
         bf16x8 ahi[2], alo[2];
 #pragma unroll
         for (int sp = 0; sp < 2; ++sp)

@@ -254,6 +254,27 @@ def test_kernel_sum_blocks(na, nb, D, off):
         assert abs(acc - want) <= (2e-6 if excl else 2e-5) * want, excl
 
 
+@pytest.mark.parametrize("nsplit", [1, 3, 5, 10, 20])
+def test_permutation_sums_symmetric_walk_for_every_split_length(nsplit, monkeypatch):
+    """The upper-triangle walk (weights 0 / 1 / 2 per tile, different for the four waves of a workgroup) against
+    the full walk, with the posterior axis cut into ranges of 20, 7, 4, 2 and 1 blocks (LVAE_NSPLIT overrides the
+    plan): label sums of tiles below the diagonal must not leak in, whatever the range length."""
+    import os
+    from lvae import estimators as E
+    monkeypatch.setenv("LVAE_NSPLIT", str(nsplit))
+    rng = np.random.default_rng(nsplit)
+    n, D, P = 640, 32, 37
+    x = dev(rng.standard_normal((n, D)).astype(np.float32))
+    labels = E.permutation_labels(n // 2, n - n // 2, P, "cuda", torch.Generator(device="cuda").manual_seed(1))
+    alphas = [0.1 * i for i in range(15)]
+    q, lr, tot = E.mmd_permutation_sums(x, 0, x, labels, alphas, 1e-5, True)
+    qf, lrf, totf = E.mmd_permutation_sums(x, 0, x, labels, alphas, 1e-5, False)
+    np.testing.assert_allclose(q.cpu().numpy(), qf.cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(lr.cpu().numpy(), lrf.cpu().numpy(), rtol=1e-6)
+    assert abs(float(tot) - float(totf)) <= 1e-6 * float(totf)
+    assert os.environ["LVAE_NSPLIT"] == str(nsplit)
+
+
 @pytest.mark.parametrize("n1,n2,D,P", [(300, 340, 32, 20), (257, 190, 64, 130), (1000, 1500, 16, 9),
                                          (200, 150, 128, 5), (2048, 2048, 32, 33), (130, 110, 250, 7)])
 def test_mmd_permutation_test_unpinned(n1, n2, D, P):
