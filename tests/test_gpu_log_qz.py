@@ -149,31 +149,39 @@ def test_q1_raises():
                               reduce_mean=True)
 
 
-def test_hip_graph_capture_and_replay():
+@pytest.mark.parametrize("N_,M_", [(700, 500), (2200, 2000)])
+def test_hip_graph_capture_and_replay(N_, M_):
     """Every entry point is asynchronous on the caller's stream, takes a caller-provided workspace and picks
     its path on the device, so a whole estimator call can be captured in a HIP graph and replayed on new
-    inputs (here through torch.cuda.CUDAGraph, which only provides the capture stream and the memory pool)."""
+    inputs (here through torch.cuda.CUDAGraph, which only provides the capture stream and the memory pool).
+    At the larger size the captured call holds both prod-marginals sweeps (matrix pipe / packed fp32) and the
+    replays take one or the other from the conditioning of the inputs."""
     from lvae import estimators as E
     rng = np.random.default_rng(11)
-    N_, M_, D = 700, 500, 32
+    D = 32
     static = [torch.zeros(N_, D, device="cuda"), torch.zeros(N_, D, device="cuda"), torch.zeros(M_, D, device="cuda")]
     E.log_qz_raw(static[0], static[1], static[2], 3.0, True)          # warm-up outside the capture
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         lq, lqpm = E.log_qz_raw(static[0], static[1], static[2], 3.0, True)
-    for trial, shift in enumerate((0.0, 30.0)):       # the second input set takes the redo / fallback branches
-        mu = rng.standard_normal((N_, D)).astype(np.float32)
-        lv = (0.5 * rng.standard_normal((N_, D)) - 1.0).astype(np.float32)
+    # the second input set takes the redo / fallback branches, the third (peaked posteriors away from the origin)
+    # fails the conditioning test: direct kernels for both outputs
+    for trial, (shift, peaked) in enumerate(((0.0, False), (30.0, False), (0.0, True))):
+        mu = rng.standard_normal((N_, D)).astype(np.float32) * (3.0 if peaked else 1.0)
+        lv = (0.5 * rng.standard_normal((N_, D)) - (10.0 if peaked else 1.0)).astype(np.float32)
         z = (rng.standard_normal((M_, D)) + shift).astype(np.float32)
+        if peaked:
+            z = (mu[rng.integers(0, N_, M_)] + np.exp(-5.0) * rng.standard_normal((M_, D))).astype(np.float32)
         for t, a in zip(static, (mu, lv, z)):
             t.copy_(torch.from_numpy(a))
         graph.replay()
         torch.cuda.synchronize()
         ref, refpm = onp.approximate_log_q_z(mu, lv, z, method="all", prod_marginals=True, reduce_mean=False)
         ref, refpm = ref - (3.0 - np.log(N_)), refpm - D * (3.0 - np.log(N_))
-        np.testing.assert_allclose(lq.cpu().numpy(), ref, rtol=1e-4, atol=1e-3, err_msg=f"trial {trial}")
-        np.testing.assert_allclose(lqpm.cpu().numpy(), refpm, rtol=1e-4, atol=1e-3, err_msg=f"trial {trial}")
+        atol = 1e-3 if not peaked else 1e-4 * float(np.abs(refpm).max())
+        np.testing.assert_allclose(lq.cpu().numpy(), ref, rtol=1e-4, atol=atol, err_msg=f"trial {trial}")
+        np.testing.assert_allclose(lqpm.cpu().numpy(), refpm, rtol=1e-4, atol=atol, err_msg=f"trial {trial}")
 
 
 def test_heterogeneous_posteriors_skip_fixed_reference():
