@@ -141,6 +141,31 @@ def test_auto_path_prod_marginals_matrix_pipe_and_its_gate(N, M, D):
     assert torch.equal(lqpm2, lqpm2d) and torch.equal(lq2, lq2d)
 
 
+def test_auto_path_prod_marginals_variance_input_and_excluded_diagonal():
+    """The matrix-pipe prod-marginals sweep behind the two other switches of the entry point: posterior spread
+    given as variance (mutual_information.py's convention) and the excluded diagonal pair (which only concerns
+    the joint density).  Checked against the forced direct path of the same call."""
+    from lvae import estimators as E
+    from lvae import _native as N_
+    g = torch.Generator(device="cuda").manual_seed(3)
+    n, D = 2100, 32
+    mu = torch.randn(n, D, device="cuda", generator=g)
+    lv = 0.4 * torch.randn(n, D, device="cuda", generator=g) - 1.5
+    z = mu[torch.randint(0, n, (2300,), device="cuda", generator=g)] + 0.5 * torch.randn(2300, D, device="cuda", generator=g)
+    a = E.log_qz_raw(mu, lv, z, 1.0, True)
+    b = E.log_qz_raw(mu, lv.exp(), z, 1.0, True, spread_kind=N_.SPREAD_VAR)
+    c = E.log_qz_raw(mu, lv.exp(), z, 1.0, True, spread_kind=N_.SPREAD_VAR, path=N_.PATH_DIRECT)
+    for k in (0, 1):
+        scale = float(a[k].abs().max())
+        assert float((a[k] - b[k]).abs().max()) <= 2e-6 * scale
+        assert float((b[k] - c[k]).abs().max()) <= 2e-6 * scale
+    d = E.log_qz_raw(mu, lv, z[:n], 1.0, True, exclude_diag=True)
+    e = E.log_qz_raw(mu, lv, z[:n], 1.0, True, exclude_diag=True, path=N_.PATH_DIRECT)
+    for k in (0, 1):
+        assert float((d[k] - e[k]).abs().max()) <= 2e-6 * float(e[k].abs().max())
+    assert not torch.equal(d[1], e[1])
+
+
 def test_q1_raises():
     from lvae import estimators as E
     g = load_golden("logqz_generic")
