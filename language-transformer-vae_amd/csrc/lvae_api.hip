@@ -282,7 +282,9 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     // conditioning test selects the direct path.
     const bool auto_gate = want_joint && joint_path == LVAE_PATH_AUTO;
     const bool dparams_now = with_pm || (want_joint && joint_path == LVAE_PATH_DIRECT);
-    LVAE_HIP(hipMemsetAsync(hdr, 0, sizeof(PairHeader), st));
+    // (the redo flags of the fixed-reference pass sit right behind the header: one fill for both)
+    LVAE_HIP(hipMemsetAsync(hdr, 0, need_mfma ? p.off_redo - p.off_hdr + (size_t)(p.cpad / 128 + 1) * sizeof(int)
+                                              : sizeof(PairHeader), st));
     if (p.DP) {
         rc = lvae_launch_colsum(mu, N, D, hdr, st);
         if (rc) return rc;
@@ -320,7 +322,6 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     int* redo = (int*)(base + p.off_redo);
     const int group_cols = 128 * p.NCB;
     if (need_mfma) {
-        LVAE_HIP(hipMemsetAsync(redo, 0, (size_t)(p.cpad / 128 + 1) * sizeof(int), st));
         if (fixed_ref) {
             rc = lvae_launch_lse_shift_bias(rbias, p.nblk * 32, N, hdr, st);
             if (rc) return rc;

@@ -129,6 +129,8 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
 
     size_t o = 0;
     p.off_hdr = o;      o = lvae_align256(o + sizeof(PairHeader));
+    p.off_redo = o;     // redo flags of the fixed-reference logsumexp pass: one int per MFMA workgroup column group
+    o = lvae_align256(o + (size_t)(p.cpad / 128 + 1) * sizeof(int));   // (right behind the header: one memset clears both)
     // (x 1.5: the experimental bf16x3 path stores three bf16 limbs per value in the same regions)
     p.off_rfrag = o;    o = lvae_align256(o + (size_t)p.nblk * (p.DP ? p.DP : 0) * 96 * sizeof(float));
     p.off_rbias = o;    o = lvae_align256(o + ((size_t)p.nblk * 32 + 64) * sizeof(float));
@@ -143,8 +145,6 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
     if (with_pm) o = lvae_align256(o + (size_t)p.dsplit * (p.DC / 16) * (p.cpad / 64) * sizeof(int));
     p.off_pmtmp = o;    // prod-marginals: per-(dimension, kept element) log-terms before the sum over dimensions
     if (with_pm) o = lvae_align256(o + (size_t)p.DC * p.cpad * sizeof(float));
-    p.off_redo = o;     // redo flags of the fixed-reference logsumexp pass: one int per MFMA workgroup column group
-    o = lvae_align256(o + (size_t)(p.cpad / 128 + 1) * sizeof(int));
     // limb operands of the experimental bf16 prod-marginals kernel (pair_pm_bx.hip): 1 KiB per posterior / sample
     p.off_pmbx_a = o;
     if (with_pm && p.DP != 0 && p.DC <= 128) o = lvae_align256(o + (size_t)p.nblk * p.DC * 1024);
