@@ -290,13 +290,15 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) cn[cb] = KS ? colnorm[col0 + cb * 32 + r] : 0.f;
     // two kernel values at a time (packed fp32 for the polynomial)
+    const float k_ne = k_nbase * k_eps;
     auto kfun2 = [&](float d2a, float d2b, float cnv) -> f32x2 {
-        const f32x2 v = {fabsf(d2a + cnv) + k_eps, fabsf(d2b + cnv) + k_eps};
         if (EPI == 1 || EPI == 2 || EPI == 5) {
-            const f32x2 a = v * (f32x2){k_nbase, k_nbase};
+            // exponent -base * (|d2 + |x|^2| + eps) in three instructions per pair of values: one packed add, then
+            // one fma each with the absolute value as an input modifier
+            const f32x2 x = (f32x2){d2a, d2b} + (f32x2){cnv, cnv};
             f32x2 t;
-            t.x = lvae_exp2(a.x);
-            t.y = lvae_exp2(a.y);
+            t.x = lvae_exp2(__builtin_fmaf(__builtin_fabsf(x.x), k_nbase, k_ne));
+            t.y = lvae_exp2(__builtin_fmaf(__builtin_fabsf(x.y), k_nbase, k_ne));
             if (EPI == 1) return __builtin_elementwise_fma((f32x2){kc[1], kc[1]}, t, (f32x2){kc[0], kc[0]});
             if (EPI == 5) {
                 const f32x2 t2 = t * t;
@@ -311,6 +313,7 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
             for (int k = 15; k >= 0; --k) pacc = __builtin_elementwise_fma(pacc, t, (f32x2){kc[k], kc[k]});
             return pacc;
         } else {
+            const f32x2 v = {fabsf(d2a + cnv) + k_eps, fabsf(d2b + cnv) + k_eps};
             f32x2 f = {0.f, 0.f};
 #pragma unroll 4
             for (int k = 0; k < KC; ++k)
