@@ -855,8 +855,8 @@ static int ksum_epi(const KsumParams& kp) {
     if (kp.n > 16) return 3;
     // coefficients in pairs (c0 = 0, c[2j+1] == c[2j+2]): the cheaper factored form, e.g. the reference's
     // bandwidths 0, 0.1 .. 1.4 (loss_and_optimisation.py:598)
-    bool paired = kp.c[0] == 0.f;
-    for (int j = 0; j < 8 && paired; ++j) paired = kp.c[2 * j + 1] == kp.c[2 * j + 2];
+    bool paired = kp.c[0] == 0.f && kp.n <= 14;
+    for (int j = 0; j < 7 && paired; ++j) paired = kp.c[2 * j + 1] == kp.c[2 * j + 2];
     return paired ? 5 : 2;
 }
 

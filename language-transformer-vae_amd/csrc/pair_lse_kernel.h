@@ -269,9 +269,10 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
     // Kernel-sum parameters, read once into (scalar) registers: EPI 1 = one bandwidth (c0 + c1*t),
     // EPI 2 = polynomial of degree <= 16 in t, fully unrolled Horner (unused high coefficients are 0),
     // EPI 3 = arbitrary bandwidths, one exponential each.
-    // EPI 5 = polynomial whose coefficients come in pairs (c0 = 0, c[2j+1] == c[2j+2] = e_j): t (1 + t) Q(t^2),
-    // ten packed operations instead of sixteen; the reference's fifteen bandwidths 0, 0.1 .. 1.4 are this case.
-    constexpr int KC = EPI == 1 ? 2 : (EPI == 2 ? 17 : (EPI == 3 ? LVAE_KSUM_MAX : (EPI == 5 ? 8 : 1)));
+    // EPI 5 = polynomial of degree <= 14 whose coefficients come in pairs (c0 = 0, c[2j+1] == c[2j+2] = e_j):
+    // t (1 + t) Q(t^2), nine packed operations instead of sixteen; the reference's fifteen bandwidths 0, 0.1 .. 1.4
+    // are this case.
+    constexpr int KC = EPI == 1 ? 2 : (EPI == 2 ? 17 : (EPI == 3 ? LVAE_KSUM_MAX : (EPI == 5 ? 7 : 1)));
     float kc[KC];
     float k_eps = 0.f, k_nbase = 0.f;
     int k_n = 0;
@@ -303,9 +304,9 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
             if (EPI == 5) {
                 const f32x2 t2 = t * t;
                 const f32x2 lin = t2 + t;                 // t (1 + t)
-                f32x2 q = {kc[7], kc[7]};
+                f32x2 q = {kc[6], kc[6]};
 #pragma unroll
-                for (int k = 6; k >= 0; --k) q = __builtin_elementwise_fma(q, t2, (f32x2){kc[k], kc[k]});
+                for (int k = 5; k >= 0; --k) q = __builtin_elementwise_fma(q, t2, (f32x2){kc[k], kc[k]});
                 return lin * q;
             }
             f32x2 pacc = {kc[16], kc[16]};
