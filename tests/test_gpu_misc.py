@@ -223,7 +223,8 @@ def test_kernel_sum_blocks(na, nb, D, off):
     #  paired polynomial with unequal pairs)
     for alphas, eps in (([0.1 * i for i in range(15)], 1e-5), ([1.0 / D ** 2], 0.0), ([0.0, 0.07, 0.19], 1e-5),
                         ([0.0, 0.0], 0.0), ([0.05, 0.1, 0.15, 0.25, 0.25, 0.8], 1e-5),
-                        ([0.03, 0.06, 0.09, 0.09, 0.12, 0.12, 0.45, 0.48], 1e-5)):
+                        ([0.03, 0.06, 0.09, 0.09, 0.12, 0.12, 0.45, 0.48], 1e-5),        # (degree 16: general form)
+                        ([0.01, 0.02, 0.03, 0.03, 0.04, 0.04, 0.13, 0.14], 1e-5)):       # (degree 14, pairs 1, 2, 0.., 1)
         d2 = eps + np.abs((a64 ** 2).sum(1)[:, None] + (b64 ** 2).sum(1)[None] - 2.0 * a64 @ b64.T)
         K = sum(np.exp(-al * d2) for al in alphas)
         for excl in (False, True):
