@@ -107,6 +107,14 @@ int lvae_kl_diag_bwd_f32(const float* mu, const float* logvar, int64_t N, int D,
  * Host only; used by the tests of the grid quantisation. */
 int lvae_plan_info(int64_t M, int64_t N, int D, int prod_marginals, int64_t* out);
 
+/* Diagnostic (no counterpart in the reference), host only: the extent in bytes of the workspace layout that an
+ * MMD entry point lays out for ONE mode, so that tests can check it against the matching *_workspace_bytes
+ * query (which must cover every mode).  kind 0: lvae_kernel_sum_f32(a [na], b [nb], symmetric); kind 1:
+ * lvae_mmd_perm_f32(cols [na], pooled [nb], symmetric); kind 2: the pass of lvae_mmd_rbf_f32(x [na], y [nb])
+ * named by `symmetric`: 0 = (x, y), 1 = (x, x), 2 = (y, y).  out[3] = {extent, reduced-axis splits, padded
+ * kept axis}. */
+int lvae_layout_info(int kind, int64_t na, int64_t nb, int D, int symmetric, int64_t* out);
+
 /* Column-sharded variant: the same reduction over the posteriors handed in, returned un-normalised as
  * (row_max, row_sum) with log_qz[i] = row_max[i] + log(row_sum[i]) - log_norm, so that partial results
  * from several devices combine with all-reduce(max) + all-reduce(sum).
@@ -192,6 +200,16 @@ int lvae_pair_bounds_f32(const float* z, const float* mu, const float* var, int6
 int lvae_log_prob_pairs_f32(const float* z, const float* mu, const float* spread, int spread_kind,
                             int64_t M, int64_t N, int D, float* out, void* stream);
 
+/* _gaussian_log_likelihood for any mask / axis (mutual_information.py:26-41): over the broadcast shape
+ * `shape[ndim]` of (sample, mu, var) the element-wise term log(2 pi var) + (sample - mu)^2 / var (mu == NULL:
+ * 0, var == NULL: 1, :32-41) is weighted with `mask` -- already unsqueezed at `dim` by the caller -- and summed
+ * over axis `dim`; out = -0.5 * that, contiguous over the shape without `dim`.  shape / st_* are HOST arrays;
+ * st_*[k] is the element stride of that operand along axis k of the broadcast shape (0 where it broadcasts).
+ * ndim <= 6. */
+int lvae_gauss_ll_masked_f32(const float* sample, const float* mu, const float* var, const float* mask, int ndim,
+                             const int64_t* shape, const int64_t* st_sample, const int64_t* st_mu,
+                             const int64_t* st_var, const int64_t* st_mask, int dim, float* out, void* stream);
+
 /* kl_divergence (loss_and_optimisation.py:14-43): kl = 0.5*(mu^2 + e^logvar - logvar - 1), hinge keeps
  * kl > lambda (:27-30; lambda <= 0: hinge == kl).  Outputs (each may be NULL): element-wise [N,D] and
  * latent-summed [N]. */
@@ -204,13 +222,15 @@ int lvae_colmean_f32(const float* x, int64_t n, int64_t c, float* out, void* ws,
                      void* stream);
 
 /* GaussianKDE.score_samples (utils_latent_analysis_optimisation.py:33-60): X [n,d] fit points, Y [m,d]
- * queries, bandwidth bw; out[j] = log(bw^-d * sum_i exp(logN((X_i - Y_j)/bw)) / n), float32.
+ * queries, bandwidth bw; out[j] = log(bw^-d * sum_i exp(logN((X_i - Y_j)/bw)) / n_norm), float32.  n_norm is
+ * the size of the FIT set (the reference divides by self.n, :58, also when score_samples is handed a batch X
+ * of another size); 0 means n.
  * stabilise == 0: plain sum like the reference (quirk Q6: -inf when every term underflows);
  * stabilise != 0 (no counterpart in the reference; for dataset-scale use): the sum is taken relative to the
  * largest term (one extra pass without exponentials), finite for any query. */
 int lvae_kde_workspace_bytes(int64_t n, int64_t m, int64_t* out_bytes);
-int lvae_kde_score_f32(const float* X, const float* Y, int64_t n, int64_t m, int d, float bw, int stabilise,
-                       float* out, void* ws, int64_t ws_bytes, void* stream);
+int lvae_kde_score_f32(const float* X, const float* Y, int64_t n, int64_t n_norm, int64_t m, int d, float bw,
+                       int stabilise, float* out, void* ws, int64_t ws_bytes, void* stream);
 
 /* Gaussian-kernel MMD two-sample statistic with a sum of bandwidths:
  *     k(a, b) = sum_k exp(-alphas[k] * (dist_eps + |a - b|^2))
@@ -246,8 +266,10 @@ int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, int64_t nb, 
  * benchmark configuration; never called by the reference itself -- PARITY UNPINNED like the statistic).
  * pooled [n,D]: both samples stacked; cols [nc,D]: the rows col_offset .. col_offset+nc-1 of it that this
  * call (this rank) owns; labels [P][n] uint8 in device memory, labels[p][i] != 0 <=> under labeling p element
- * i belongs to sample 1 (P <= 128 per call).  With K the pooled kernel matrix of lvae_mmd_rbf_f32 (alpha > 0
- * bandwidths only -- alpha = 0 adds exactly 0 to the statistic -- diagonal excluded), L_p the indicator
+ * i belongs to sample 1 (P <= 128 per call).  With K the pooled kernel matrix of lvae_mmd_rbf_f32 restricted to
+ * the alpha > 0 bandwidths (an alpha = 0 bandwidth adds 1 to every pair, which cancels exactly in the statistic,
+ * and is LEFT OUT of q, lr and T here -- unlike lvae_kernel_sum_f32, which counts it; do not mix the two),
+ * diagonal excluded, L_p the indicator
  * vector of labeling p and r = K 1, out receives 2P+1 float64:
  *     out[p]      = sum over owned columns c of L_p[c] * (K L_p)[c]      (q_p; all columns: L_p^T K L_p)
  *     out[P + p]  = sum over owned columns c of L_p[c] * r[c]

@@ -59,11 +59,14 @@ _SIGNATURES = {
     "lvae_get_pair_math": (_int, []),
     "lvae_log_prob_pairs_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _int, _i64, _i64, _int, _c_f32p,
                                        ctypes.c_void_p]),
+    "lvae_gauss_ll_masked_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _int, ctypes.POINTER(_i64),
+                                        ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64),
+                                        ctypes.POINTER(_i64), _int, _c_f32p, ctypes.c_void_p]),
     "lvae_kl_diag_f32": (_int, [_c_f32p, _c_f32p, _i64, _int, _f32, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
                                 ctypes.c_void_p]),
     "lvae_colmean_f32": (_int, [_c_f32p, _i64, _i64, _c_f32p, ctypes.c_void_p, _i64, ctypes.c_void_p]),
     "lvae_kde_workspace_bytes": (_int, [_i64, _i64, ctypes.POINTER(_i64)]),
-    "lvae_kde_score_f32": (_int, [_c_f32p, _c_f32p, _i64, _i64, _int, _f32, _int, _c_f32p, ctypes.c_void_p, _i64,
+    "lvae_kde_score_f32": (_int, [_c_f32p, _c_f32p, _i64, _i64, _i64, _int, _f32, _int, _c_f32p, ctypes.c_void_p, _i64,
                                   ctypes.c_void_p]),
     "lvae_mmd_workspace_bytes": (_int, [_i64, _i64, _int, ctypes.POINTER(_i64)]),
     "lvae_mmd_rbf_f32": (_int, [_c_f32p, _c_f32p, _i64, _i64, _int, ctypes.POINTER(_f32), _int, _f32, _int,
@@ -82,6 +85,7 @@ _SIGNATURES = {
     "lvae_kl_diag_bwd_f32": (_int, [_c_f32p, _c_f32p, _i64, _int, _f32, _c_f32p, _c_f32p, _int, _c_f32p,
                                     _c_f32p, ctypes.c_void_p]),
     "lvae_plan_info": (_int, [_i64, _i64, _int, _int, ctypes.POINTER(_i64)]),
+    "lvae_layout_info": (_int, [_int, _i64, _i64, _int, _int, ctypes.POINTER(_i64)]),
     "lvae_mmd_perm_workspace_bytes": (_int, [_i64, _i64, _int, ctypes.POINTER(_i64)]),
     "lvae_mmd_perm_f32": (_int, [_c_f32p, _i64, _i64, _c_f32p, _i64, _int, ctypes.c_void_p, _int,
                                  ctypes.POINTER(_f32), _int, _f32, _int, ctypes.c_void_p, ctypes.c_void_p, _i64,

@@ -61,7 +61,7 @@ int lvae_launch_kl(const float* mu, const float* logvar, int64_t n, int D, float
                    float* hinge_elem, float* kl_row, float* hinge_row, hipStream_t st);
 int lvae_launch_colmean(const float* x, int64_t n, int64_t c, float* out, double* acc, hipStream_t st);
 void lvae_kde_plan(int64_t n, int64_t m, int* nsplit, int64_t* rows);
-int lvae_launch_kde(const float* X, const float* Y, int64_t n, int64_t m, int d, float bw, int stabilise,
+int lvae_launch_kde(const float* X, const float* Y, int64_t n, int64_t n_norm, int64_t m, int d, float bw, int stabilise,
                     float* out, float* ws, hipStream_t st);
 int lvae_launch_pair_matrix(const float* a, const float* spread, int spread_kind, const float* b,
                             int64_t na, int64_t nb, int D, int mode, const PairHeader* hdr, float* out,
@@ -123,6 +123,10 @@ int lvae_launch_pair_bf16x3_perm(const PairPlan& p, const float* rfrag, const fl
 int lvae_launch_prep_bf16x3(int src, bool frag, const float* x, const float* spread, int spread_kind,
                             int64_t n, int64_t npad, int D, int DP, const PairHeader* hdr, int64_t ngauss,
                             void* out, hipStream_t st);
+int lvae_launch_gauss_ll_masked(const float* sample, const float* mu, const float* var, const float* mask, int ndim,
+                                const int64_t* shape, const int64_t* st_s, const int64_t* st_mu,
+                                const int64_t* st_var, const int64_t* st_mask, int dim, int64_t n_out, float* out,
+                                hipStream_t st);
 int lvae_launch_mmd_stat(const double* sums, int64_t n1, int64_t n2, int unbiased, int zero_alphas,
                          double* out, hipStream_t st);
 
@@ -714,6 +718,26 @@ extern "C" int lvae_log_prob_pairs_f32(const float* z, const float* mu, const fl
     return lvae_launch_pair_matrix(mu, spread, spread_kind, z, N, M, D, 0, nullptr, out, (hipStream_t)stream);
 }
 
+extern "C" int lvae_gauss_ll_masked_f32(const float* sample, const float* mu, const float* var, const float* mask,
+                                        int ndim, const int64_t* shape, const int64_t* st_sample,
+                                        const int64_t* st_mu, const int64_t* st_var, const int64_t* st_mask, int dim,
+                                        float* out, void* stream) {
+    LVAE_CHECK_ARG(sample && mask && out && shape && st_sample && st_mask, "sample, mask, out, shape and strides must be non-NULL");
+    LVAE_CHECK_ARG(ndim >= 1 && ndim <= 6, "need 1 <= ndim <= 6 (got %d)", ndim);
+    LVAE_CHECK_ARG(dim >= 0 && dim < ndim, "dim must name an axis of the broadcast shape");
+    LVAE_CHECK_ARG((!mu || st_mu) && (!var || st_var), "strides missing for mu / var");
+    int64_t n_out = 1;
+    for (int k = 0; k < ndim; ++k) {
+        LVAE_CHECK_ARG(shape[k] >= 1 && shape[k] < (1LL << 31), "bad extent on axis %d", k);
+        LVAE_CHECK_ARG(st_sample[k] >= 0 && st_mask[k] >= 0 && (!mu || st_mu[k] >= 0) && (!var || st_var[k] >= 0),
+                       "strides must be non-negative");
+        if (k != dim) n_out *= shape[k];
+        LVAE_CHECK_ARG(n_out < (1LL << 40), "output too large");
+    }
+    return lvae_launch_gauss_ll_masked(sample, mu, var, mask, ndim, shape, st_sample, st_mu, st_var, st_mask, dim,
+                                       n_out, out, (hipStream_t)stream);
+}
+
 // ---- KL, column means, KDE --------------------------------------------------------------------------
 extern "C" int lvae_kl_diag_f32(const float* mu, const float* logvar, int64_t N, int D, float lambda,
                                 float* kl_elem, float* hinge_elem, float* kl_row, float* hinge_row,
@@ -744,17 +768,19 @@ extern "C" int lvae_kde_workspace_bytes(int64_t n, int64_t m, int64_t* out_bytes
     return LVAE_OK;
 }
 
-extern "C" int lvae_kde_score_f32(const float* X, const float* Y, int64_t n, int64_t m, int d, float bw,
-                                  int stabilise, float* out, void* ws, int64_t ws_bytes, void* stream) {
+extern "C" int lvae_kde_score_f32(const float* X, const float* Y, int64_t n, int64_t n_norm, int64_t m, int d,
+                                  float bw, int stabilise, float* out, void* ws, int64_t ws_bytes, void* stream) {
     LVAE_CHECK_ARG(X && Y && out, "NULL pointer");
     LVAE_CHECK_ARG(n >= 1 && m >= 1 && d >= 1, "need n, m, d >= 1");
+    LVAE_CHECK_ARG(n_norm >= 0, "n_norm must be >= 0 (0: normalise by n)");
+    if (n_norm == 0) n_norm = n;
     LVAE_CHECK_ARG(bw > 0.f, "bandwidth must be positive");
     int nsplit;
     int64_t rows;
     lvae_kde_plan(n, m, &nsplit, &rows);
     int rc = check_ws(ws, ws_bytes, ((size_t)nsplit + 1) * m * sizeof(float));
     if (rc) return rc;
-    return lvae_launch_kde(X, Y, n, m, d, bw, stabilise, out, (float*)ws, (hipStream_t)stream);
+    return lvae_launch_kde(X, Y, n, n_norm, m, d, bw, stabilise, out, (float*)ws, (hipStream_t)stream);
 }
 
 // ---- Categorical MI bounds, KS statistic -------------------------------------------------------------------
@@ -839,12 +865,26 @@ static int build_ksum(const float* alphas, int n_alpha, float eps, KsumParams* k
     return LVAE_OK;
 }
 
+// Workspace of one kernel-sum pass (kept = a [na], reduced = b [nb]).  The split search of the plan is not
+// monotone in the shape or in `sym`, so every size below is the extent of the plan that will actually be laid
+// out (or the maximum over the plans a call may lay out), never a "largest case" guess.
+static size_t ksum_pass_extent(int64_t na, int64_t nb, int D, bool sym) {
+    return lvae_make_pair_plan(nb, na, ksum_plan_dim(D), false, 0, sym).total;
+}
+
+// lvae_mmd_rbf_f32 runs three passes in one workspace: (x, x) and (y, y) symmetric, (x, y) plain.
+static size_t mmd_pair_extent(int64_t n1, int64_t n2, int D) {
+    size_t e = ksum_pass_extent(n1, n1, D, true);
+    const size_t e2 = ksum_pass_extent(n2, n2, D, true), e3 = ksum_pass_extent(n1, n2, D, false);
+    if (e2 > e) e = e2;
+    if (e3 > e) e = e3;
+    return e;
+}
+
 extern "C" int lvae_mmd_workspace_bytes(int64_t n1, int64_t n2, int D, int64_t* out_bytes) {
     LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
     LVAE_CHECK_ARG(n1 >= 2 && n2 >= 2 && D >= 1, "need n1, n2 >= 2 and D >= 1");
-    const int64_t nm = n1 > n2 ? n1 : n2;
-    const PairPlan p = lvae_make_pair_plan(nm, nm, ksum_plan_dim(D), false, 0, true);
-    *out_bytes = (int64_t)(p.total + 256);
+    *out_bytes = (int64_t)(mmd_pair_extent(n1, n2, D) + 256);
     return LVAE_OK;
 }
 
@@ -894,8 +934,11 @@ static int prep_ksum_operands(const PairPlan& p, bool bx, const float* a, int64_
 }
 
 static int ksum_pass(const float* a, int64_t na, const float* b, int64_t nb, int D, bool excl, int epi,
-                     void* ws, double* out, hipStream_t st) {
+                     void* ws, size_t ws_extent, double* out, hipStream_t st) {
     const PairPlan p = lvae_make_pair_plan(nb, na, ksum_plan_dim(D), false, 0, a == b);
+    if (p.total > ws_extent)
+        return lvae_set_error(LVAE_ERR_WORKSPACE, "internal: kernel-sum pass needs %zu bytes, %zu reserved", p.total,
+                              ws_extent);
     char* base = (char*)ws;
     PairHeader* hdr = (PairHeader*)(base + p.off_hdr);
     float* rfrag = (float*)(base + p.off_rfrag);
@@ -929,12 +972,11 @@ extern "C" int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int6
     int rc = build_ksum(alphas, n_alpha, dist_eps, &kp, &zeros);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const int64_t nm = n1 > n2 ? n1 : n2;
-    const PairPlan pmax = lvae_make_pair_plan(nm, nm, ksum_plan_dim(D), false, 0, true);
-    rc = check_ws(ws, ws_bytes, pmax.total + 256);
+    const size_t extent = mmd_pair_extent(n1, n2, D);
+    rc = check_ws(ws, ws_bytes, extent + 256);
     if (rc) return rc;
     PairHeader* hdr = (PairHeader*)ws;
-    double* sums = (double*)((char*)ws + pmax.total);        // 3 float64 behind the pair workspace
+    double* sums = (double*)((char*)ws + extent);            // 3 float64 behind the pair workspace
     LVAE_HIP(hipMemsetAsync(hdr, 0, sizeof(PairHeader), st));   // colsum = 0 -> no centering shift
     rc = lvae_launch_set_ksum(hdr, kp, st);
     if (rc) return rc;
@@ -943,11 +985,11 @@ extern "C" int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int6
         LVAE_HIP(hipMemsetAsync(sums, 0, 3 * sizeof(double), st));
     } else {
         const int epi = ksum_epi(kp);
-        rc = ksum_pass(x, n1, x, n1, D, excl, epi, ws, sums + 0, st);
+        rc = ksum_pass(x, n1, x, n1, D, excl, epi, ws, extent, sums + 0, st);
         if (rc) return rc;
-        rc = ksum_pass(y, n2, y, n2, D, excl, epi, ws, sums + 1, st);
+        rc = ksum_pass(y, n2, y, n2, D, excl, epi, ws, extent, sums + 1, st);
         if (rc) return rc;
-        rc = ksum_pass(x, n1, y, n2, D, false, epi, ws, sums + 2, st);
+        rc = ksum_pass(x, n1, y, n2, D, false, epi, ws, extent, sums + 2, st);
         if (rc) return rc;
     }
     return lvae_launch_mmd_stat(sums, n1, n2, unbiased, zeros, out, st);
@@ -956,8 +998,8 @@ extern "C" int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int6
 extern "C" int lvae_kernel_sum_workspace_bytes(int64_t na, int64_t nb, int D, int64_t* out_bytes) {
     LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
     LVAE_CHECK_ARG(na >= 1 && nb >= 1 && D >= 1, "need na, nb, D >= 1");
-    const PairPlan p = lvae_make_pair_plan(nb, na, ksum_plan_dim(D), false, 0, true);     // the finer (symmetric) plan is the larger
-    *out_bytes = (int64_t)p.total;
+    const size_t e0 = ksum_pass_extent(na, nb, D, false), e1 = ksum_pass_extent(na, nb, D, true);
+    *out_bytes = (int64_t)(e0 > e1 ? e0 : e1);     // serves either mode (neither plan is always the larger)
     return LVAE_OK;
 }
 
@@ -1015,12 +1057,18 @@ extern "C" int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, i
 // workspace: pair plan | label fragments | diagonal-tile column sums [nsplit][cpad] | 256 float64
 static size_t perm_labfrag_bytes(const PairPlan& p) { return lvae_align256((size_t)p.nblk * 512 * 16); }
 static size_t perm_diag_bytes(const PairPlan& p) { return lvae_align256((size_t)p.nsplit * p.cpad * sizeof(double)); }
+static PairPlan perm_plan(int64_t nc, int64_t n, int D, bool sym) {
+    return lvae_make_pair_plan(n, nc, ksum_plan_dim(D), false, 1, sym);
+}
+static size_t perm_extent(const PairPlan& p) {
+    return p.total + perm_labfrag_bytes(p) + perm_diag_bytes(p) + 256 * sizeof(double);
+}
 
 extern "C" int lvae_mmd_perm_workspace_bytes(int64_t nc, int64_t n, int D, int64_t* out_bytes) {
     LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
     LVAE_CHECK_ARG(nc >= 1 && n >= 2 && D >= 1, "need nc >= 1, n >= 2, D >= 1");
-    const PairPlan p = lvae_make_pair_plan(n, nc, ksum_plan_dim(D), false, 1, true);
-    *out_bytes = (int64_t)(p.total + perm_labfrag_bytes(p) + perm_diag_bytes(p) + 256 * sizeof(double));
+    const size_t e0 = perm_extent(perm_plan(nc, n, D, false)), e1 = perm_extent(perm_plan(nc, n, D, true));
+    *out_bytes = (int64_t)(e0 > e1 ? e0 : e1);     // serves either mode
     return LVAE_OK;
 }
 
@@ -1039,13 +1087,13 @@ extern "C" int lvae_mmd_perm_f32(const float* cols, int64_t nc, int64_t col_offs
     int zeros = 0;
     int rc = build_ksum(alphas, n_alpha, dist_eps, &kp, &zeros);
     if (rc) return rc;
+    (void)zeros;      // alpha == 0 bandwidths are left out of q, lr and T (lvae.h): they cancel in the statistic
     hipStream_t st = (hipStream_t)stream;
     const int sym = symmetric != 0;
-    const PairPlan p = lvae_make_pair_plan(n, nc, ksum_plan_dim(D), false, 1, sym);
-    const PairPlan pmax = lvae_make_pair_plan(n, nc, ksum_plan_dim(D), false, 1, true);
+    const PairPlan p = perm_plan(nc, n, D, sym);
     const size_t lab_bytes = perm_labfrag_bytes(p);
     const size_t diag_bytes = perm_diag_bytes(p);
-    rc = check_ws(ws, ws_bytes, pmax.total + perm_labfrag_bytes(pmax) + perm_diag_bytes(pmax) + 256 * sizeof(double));
+    rc = check_ws(ws, ws_bytes, perm_extent(p));      // the extent of the layout used below, not of another mode's plan
     if (rc) return rc;
     char* base = (char*)ws;
     PairHeader* hdr = (PairHeader*)(base + p.off_hdr);
@@ -1083,6 +1131,29 @@ extern "C" int lvae_mmd_perm_f32(const float* cols, int64_t nc, int64_t col_offs
     if (rc) return rc;
     return lvae_launch_perm_lr((const double*)partial, diag_partial, p.nsplit, p.cpad, nc, labels, n, col_offset,
                                P, sym, qperm, out, st);
+}
+
+// Diagnostic, host only: the extent of the workspace layout an entry point uses for one mode.
+extern "C" int lvae_layout_info(int kind, int64_t na, int64_t nb, int D, int symmetric, int64_t* out) {
+    LVAE_CHECK_ARG(out, "out is NULL");
+    LVAE_CHECK_ARG(na >= 1 && nb >= 1 && D >= 1, "need na, nb, D >= 1");
+    const bool sym = symmetric != 0;
+    if (kind == 0) {
+        const PairPlan p = lvae_make_pair_plan(nb, na, ksum_plan_dim(D), false, 0, sym);
+        out[0] = (int64_t)p.total; out[1] = p.nsplit; out[2] = p.cpad;
+    } else if (kind == 1) {
+        const PairPlan p = perm_plan(na, nb, D, sym);
+        out[0] = (int64_t)perm_extent(p); out[1] = p.nsplit; out[2] = p.cpad;
+    } else if (kind == 2) {
+        // the pass of lvae_mmd_rbf_f32 selected by `symmetric`: 0 = (x, y), 1 = (x, x), 2 = (y, y)
+        const PairPlan p = symmetric == 0 ? lvae_make_pair_plan(nb, na, ksum_plan_dim(D), false, 0, false)
+                         : symmetric == 1 ? lvae_make_pair_plan(na, na, ksum_plan_dim(D), false, 0, true)
+                                          : lvae_make_pair_plan(nb, nb, ksum_plan_dim(D), false, 0, true);
+        out[0] = (int64_t)p.total + 256; out[1] = p.nsplit; out[2] = p.cpad;
+    } else {
+        return lvae_set_error(LVAE_ERR_INVALID, "unknown layout kind %d", kind);
+    }
+    return LVAE_OK;
 }
 
 extern "C" int lvae_kernel_matrix_f32(const float* x, const float* y, int64_t n1, int64_t n2, int D,

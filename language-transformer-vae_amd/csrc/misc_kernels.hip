@@ -189,7 +189,7 @@ void lvae_kde_plan(int64_t n, int64_t m, int* nsplit, int64_t* rows) {
     *nsplit = (int)lvae_ceil_div(n, r);
 }
 
-int lvae_launch_kde(const float* X, const float* Y, int64_t n, int64_t m, int d, float bw, int stabilise,
+int lvae_launch_kde(const float* X, const float* Y, int64_t n, int64_t n_norm, int64_t m, int d, float bw, int stabilise,
                     float* out, float* ws, hipStream_t st) {
     int nsplit;
     int64_t rows;
@@ -197,7 +197,7 @@ int lvae_launch_kde(const float* X, const float* Y, int64_t n, int64_t m, int d,
     float* partial = ws;
     float* ref = ws + (size_t)nsplit * m;
     const float c0 = -0.5f * (float)d * LVAE_LOG_2PI * LVAE_LOG2E;
-    const float log_scale_over_n = -(float)d * logf(bw) - logf((float)n);
+    const float log_scale_over_n = -(float)d * logf(bw) - logf((float)n_norm);
     int rc;
     if (stabilise) {
         rc = kde_pass(true, X, Y, n, m, d, bw, nsplit, rows, nullptr, partial, st);
@@ -522,6 +522,72 @@ int lvae_launch_ksum_wide(const float* a, const float* b, int64_t na, int64_t nb
     const dim3 grid((unsigned)lvae_ceil_div(cpad, 32), (unsigned)nsplit);
     hipLaunchKernelGGL(ksum_wide_kernel, grid, dim3(256), 0, st, a, b, na, nb, D, hdr, excl ? 1 : 0, excl_offset, tps,
                        partial, cpad);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+// ---- _gaussian_log_likelihood in full generality (mutual_information.py:26-41) ---------------------------
+// The element-wise term of the branch named by which of mu / var is given, over the BROADCAST shape of
+// (sample, mu, var), times a mask that was unsqueezed at `dim`, summed over `dim`.  Operands come as element
+// strides over the broadcast shape (0 on broadcast axes), nothing is materialised.  One lane per output
+// element (the broadcast shape without `dim`, row-major); sized for the small tensors the reference hands it.
+#define LVAE_GLL_MAX_DIMS 6
+struct GllArgs {
+    int ndim, dim;
+    int64_t shape[LVAE_GLL_MAX_DIMS];
+    int64_t st_s[LVAE_GLL_MAX_DIMS], st_mu[LVAE_GLL_MAX_DIMS], st_var[LVAE_GLL_MAX_DIMS], st_mask[LVAE_GLL_MAX_DIMS];
+};
+
+__global__ void __launch_bounds__(256) gauss_ll_masked_kernel(const float* __restrict__ sample,
+                                                              const float* __restrict__ mu,
+                                                              const float* __restrict__ var,
+                                                              const float* __restrict__ mask, const GllArgs a,
+                                                              int64_t n_out, float* __restrict__ out) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_out) return;
+    int64_t rem = o, os = 0, om = 0, ov = 0, ok = 0;
+    for (int k = a.ndim - 1; k >= 0; --k) {
+        if (k == a.dim) continue;
+        const int64_t i = rem % a.shape[k];
+        rem /= a.shape[k];
+        os += i * a.st_s[k];
+        om += i * a.st_mu[k];
+        ov += i * a.st_var[k];
+        ok += i * a.st_mask[k];
+    }
+    const int64_t L = a.shape[a.dim];
+    float acc = 0.f;
+    for (int64_t i = 0; i < L; ++i) {
+        const float s = sample[os + i * a.st_s[a.dim]];
+        const float c = mu ? s - mu[om + i * a.st_mu[a.dim]] : s;
+        float t;
+        if (var) {
+            const float v = var[ov + i * a.st_var[a.dim]];
+            t = logf(6.283185307179586f * v) + c * c / v;          // :36, :41
+        } else {
+            t = LVAE_LOG_2PI + c * c;                              // :34, :38
+        }
+        acc += t * mask[ok + i * a.st_mask[a.dim]];
+    }
+    out[o] = -0.5f * acc;
+}
+
+int lvae_launch_gauss_ll_masked(const float* sample, const float* mu, const float* var, const float* mask, int ndim,
+                                const int64_t* shape, const int64_t* st_s, const int64_t* st_mu,
+                                const int64_t* st_var, const int64_t* st_mask, int dim, int64_t n_out, float* out,
+                                hipStream_t st) {
+    GllArgs a{};
+    a.ndim = ndim;
+    a.dim = dim;
+    for (int k = 0; k < ndim; ++k) {
+        a.shape[k] = shape[k];
+        a.st_s[k] = st_s[k];
+        a.st_mu[k] = mu ? st_mu[k] : 0;
+        a.st_var[k] = var ? st_var[k] : 0;
+        a.st_mask[k] = st_mask[k];
+    }
+    hipLaunchKernelGGL(gauss_ll_masked_kernel, dim3((unsigned)lvae_ceil_div(n_out, 256)), dim3(256), 0, st, sample,
+                       mu, var, mask, a, n_out, out);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }

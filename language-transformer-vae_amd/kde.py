@@ -19,7 +19,8 @@ class GaussianKDE:
 
     def score_samples(self, Y, X=None, stabilise=False):
         """:33-60 -- log kernel density estimate of every row of Y [m, d]; unstabilised like the
-        reference (quirk Q6: -inf when every kernel term underflows) unless ``stabilise`` is set."""
+        reference (quirk Q6: -inf when every kernel term underflows) unless ``stabilise`` is set.  A batch ``X``
+        is normalised by ``self.n``, the size of the fit set, like the reference (:58)."""
         if X is None:
             X = self.X
         Xc, Yc = N.as_f32(X, "X"), N.as_f32(Y, "Y")
@@ -31,7 +32,7 @@ class GaussianKDE:
             nbytes = N._i64(0)
             N.check(N.lib().lvae_kde_workspace_bytes(Xc.shape[0], Yc.shape[0], nbytes))
             ws = N.workspace(nbytes.value, dev)
-            N.check(N.lib().lvae_kde_score_f32(N.ptr(Xc), N.ptr(Yc), Xc.shape[0], Yc.shape[0], Xc.shape[1],
+            N.check(N.lib().lvae_kde_score_f32(N.ptr(Xc), N.ptr(Yc), Xc.shape[0], int(self.n), Yc.shape[0], Xc.shape[1],
                                                float(self.bw), int(bool(stabilise)), N.ptr(out), N.ptr(ws),
                                                nbytes.value, N.stream_ptr(dev)))
         return out

@@ -19,24 +19,50 @@ def _spread_pairs(z, mu, spread, spread_kind):
 
 
 def _gaussian_log_likelihood(sample, mask=None, dim=2, mu=None, var=None):
-    """mutual_information.py:26-41 for the layout q_z_estimate uses: sample [S,1,D] (or [S,D]) against
-    [N,D] parameters, mask == [[1.]], dim == 2 -> [S,N] ([S,1] when no parameters are given).  Missing mu
-    / var mean standard ones (:32-39)."""
-    s = sample.reshape(sample.shape[0], sample.shape[-1])
-    if mask is not None and not bool((mask == 1).all()):
-        raise NotImplementedError("only the all-ones mask the reference uses is supported")
-    if dim != 2:
-        raise NotImplementedError("only dim=2 (the latent axis of [S,1,D]) is supported")
-    S, D = s.shape
-    if mu is None and var is None:
-        mu_, var_ = torch.zeros(1, D, device=s.device), torch.ones(1, D, device=s.device)
-    elif mu is None:
-        mu_, var_ = torch.zeros_like(var), var
-    elif var is None:
-        mu_, var_ = mu, torch.ones_like(mu)
-    else:
-        mu_, var_ = mu, var
-    return _spread_pairs(s, mu_, var_, N.SPREAD_VAR).t().contiguous()
+    """mutual_information.py:26-41.  The element-wise Gaussian term over the broadcast shape of (sample, mu,
+    var), weighted with ``mask.unsqueeze(dim)`` and summed over ``dim``; missing mu / var mean standard ones
+    (:32-39).  The layout q_z_estimate uses -- sample [S,1,D] against [N,D] parameters, mask [[1.]], dim 2 ->
+    [S,N] -- goes through the pair-matrix kernel; every other mask / axis / layout through
+    lvae_gauss_ll_masked_f32 (operands passed as broadcast strides, nothing materialised)."""
+    if mask is None:
+        mask = torch.ones(1, 1, device=sample.device)
+    pair_layout = (dim == 2 and sample.dim() == 3 and sample.shape[1] == 1 and mask.numel() == 1
+                   and (mu is None or mu.dim() == 2) and (var is None or var.dim() == 2)
+                   and (mu is not None or var is not None) and float(mask.reshape(-1)[0]) == 1.0)
+    if pair_layout:
+        s = sample.reshape(sample.shape[0], sample.shape[-1])
+        if mu is None:
+            mu_, var_ = torch.zeros_like(var), var
+        elif var is None:
+            mu_, var_ = mu, torch.ones_like(mu)
+        else:
+            mu_, var_ = mu, var
+        return _spread_pairs(s, mu_, var_, N.SPREAD_VAR).t().contiguous()
+    s = N.as_f32(sample, "sample")
+    ops = [s] + [N.as_f32(t, n) for t, n in ((mu, "mu"), (var, "var")) if t is not None]
+    full = torch.broadcast_shapes(*[t.shape for t in ops])
+    nd = len(full)
+    if nd < 1 or nd > 6:
+        raise ValueError("the broadcast shape of sample / mu / var must have 1..6 axes")
+    ax = dim if dim >= 0 else nd + dim
+    if not 0 <= ax < nd:
+        raise IndexError(f"dim {dim} out of range for the broadcast shape {tuple(full)}")
+    m = N.as_f32(mask, "mask").unsqueeze(dim)           # :34-41, mask.unsqueeze(dim)
+    full = torch.broadcast_shapes(full, m.shape)
+    if len(full) != nd:
+        raise ValueError("mask.unsqueeze(dim) must not add axes to the broadcast shape")
+    arr = lambda v: (N._i64 * nd)(*[int(x) for x in v])
+    strides = lambda t: None if t is None else arr(N.as_f32(t, "operand").expand(full).stride())
+    mu_c = None if mu is None else N.as_f32(mu, "mu")
+    var_c = None if var is None else N.as_f32(var, "var")
+    out_shape = [full[k] for k in range(nd) if k != ax]
+    dev = s.device
+    with torch.cuda.device(dev):
+        out = torch.empty(out_shape, dtype=torch.float32, device=dev)
+        N.check(N.lib().lvae_gauss_ll_masked_f32(N.ptr(s), N.ptr(mu_c), N.ptr(var_c), N.ptr(m), nd, arr(full),
+                                                 strides(s), strides(mu_c), strides(var_c), strides(m), ax,
+                                                 N.ptr(out), N.stream_ptr(dev)))
+    return out
 
 
 def q_z_estimate(z, mu, var, device=None):

@@ -164,6 +164,23 @@ def gaussian_log_likelihood(sample, mu=None, var=None):
     return -0.5 * np.sum(np.log(2 * np.pi * var)[None] + (s - mu[None]) ** 2 / var[None], axis=2)
 
 
+def gaussian_log_likelihood_masked(sample, mask, dim, mu=None, var=None):
+    """mutual_information.py:26-41 in full generality: the element-wise term of the branch selected by which of
+    mu / var is given, times ``mask`` with a singleton axis inserted at ``dim``, summed over ``dim``
+    (NumPy broadcasting == torch broadcasting)."""
+    s, m = _f64(sample), _f64(mask)
+    if mu is None and var is None:
+        t = LOG_2PI + s ** 2                                                # :34
+    elif mu is None:
+        t = np.log(2 * math.pi * _f64(var)) + s ** 2 / _f64(var)            # :36
+    elif var is None:
+        t = LOG_2PI + (s - _f64(mu)) ** 2                                   # :38
+    else:
+        t = np.log(2 * math.pi * _f64(var)) + (s - _f64(mu)) ** 2 / _f64(var)   # :41
+    me = np.expand_dims(m, dim if dim >= 0 else m.ndim + 1 + dim)
+    return -0.5 * (t * me).sum(axis=dim)
+
+
 def q_z_estimate(z, mu, var):
     """mutual_information.py:44-52.  Quirk Q2: the logsumexp runs over dim=1 of [1,S,N], i.e. the
     SAMPLE axis, so the result is [1,N]: LSE_i log q(z_i|x_j) - log N per posterior j."""
@@ -270,12 +287,16 @@ def scott_bandwidth(n, d):
     return n ** (-1.0 / (d + 4))
 
 
-def kde_score_samples(X, Y, bw):
+def kde_score_samples(X, Y, bw, n_fit=None):
     """utils_latent_analysis_optimisation.py:55-58.  Quirk Q6: exp -> sum -> log with no
     stabilisation, so a query far from every point scores -inf.  To mirror the reference's float32
-    underflow the kernel values are flushed where a float32 exp would underflow to zero."""
+    underflow the kernel values are flushed where a float32 exp would underflow to zero.
+    ``n_fit``: the reference divides by self.n, the size of the set the estimator was CONSTRUCTED on, also
+    when score_samples is handed a batch X of another size (:58)."""
     X, Y = _f64(X), _f64(Y)
     n, d = X.shape
+    if n_fit is not None:
+        n = n_fit
     u = (X[:, None, :] - Y[None, :, :]) / bw                        # [n,m,d]
     logk = -0.5 * (u ** 2).sum(axis=2) - 0.5 * d * LOG_2PI
     k = np.exp(logk)

@@ -234,6 +234,60 @@ def case_kde(lo, kde, seed):
     print("wrote kde")
 
 
+def case_kde_batch(kde, seed):
+    """score_samples(Y, X=batch): the reference still divides by self.n, the size of the FIT set
+    (utils_latent_analysis_optimisation.py:58)."""
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(512, 1, generator=g) * 1.1
+    Y = torch.randn(90, 1, generator=g)
+    k = kde.GaussianKDE(X=X, bw="scott", device="cpu")
+    out = {"X": np32(X), "Y": np32(Y), "bw": np.float64(k.bw),
+           "score_full": np32(k.score_samples(Y)),
+           "score_batch_128": np32(k.score_samples(Y, X=X[:128])),
+           "score_batch_tail": np32(k.score_samples(Y, X=X[300:]))}
+    X2 = torch.randn(300, 2, generator=g)
+    Y2 = torch.randn(40, 2, generator=g)
+    k2 = kde.GaussianKDE(X=X2, bw=0.4, device="cpu")
+    out.update(X2=np32(X2), Y2=np32(Y2), score2_batch_77=np32(k2.score_samples(Y2, X=X2[:77])))
+    np.savez_compressed(os.path.join(OUT, "kde_batch.npz"), **out)
+    print("wrote kde_batch")
+
+
+def case_gll_generic(mi, seed):
+    """_gaussian_log_likelihood (mutual_information.py:26-41) away from the one layout q_z_estimate uses:
+    non-trivial masks, other reduction axes, 2-D samples."""
+    g = torch.Generator().manual_seed(seed)
+    S, N, D = 37, 21, 12
+    z = torch.randn(S, D, generator=g)
+    mu = torch.randn(N, D, generator=g)
+    var = (0.4 * torch.randn(N, D, generator=g)).exp()
+    mask_sn = (torch.rand(S, N, generator=g) > 0.3).float()          # one weight per (sample, posterior) pair
+    mask_sd = torch.rand(S, D, generator=g)                           # dim=1: weights per (sample, dimension)
+    mask_nd = (torch.rand(N, D, generator=g) > 0.5).float()          # dim=0: weights per (posterior, dimension)
+    f = mi._gaussian_log_likelihood
+    out = {"z": np32(z), "mu": np32(mu), "var": np32(var), "mask_sn": np32(mask_sn), "mask_sd": np32(mask_sd),
+           "mask_nd": np32(mask_nd),
+           "a_full_dim2": np32(f(z.unsqueeze(1), mask_sn, 2, mu=mu, var=var)),        # [S,N]
+           "a_nomu_dim2": np32(f(z.unsqueeze(1), mask_sn, 2, mu=None, var=var)),
+           "a_novar_dim2": np32(f(z.unsqueeze(1), mask_sn, 2, mu=mu, var=None)),
+           "a_std_dim2": np32(f(z.unsqueeze(1), mask_sn[:, :1], 2)),                  # [S,1]
+           "b_full_dim1": np32(f(z.unsqueeze(1), mask_sd, 1, mu=mu, var=var)),        # [S,D]: summed over posteriors
+           "c_full_dim0": np32(f(z.unsqueeze(1), mask_nd, 0, mu=mu, var=var))}        # [N,D]: summed over samples
+    # 2-D layout of the function's origin (sentence x position): sample, mu, var [B,L], mask [B,L], dim=1... the
+    # mask is unsqueezed at `dim`, so a [B] mask with dim=1 weights whole rows
+    B, L = 19, 9
+    s2 = torch.randn(B, L, generator=g)
+    mu2 = torch.randn(B, L, generator=g)
+    var2 = (0.3 * torch.randn(B, L, generator=g)).exp()
+    mask_b = (torch.rand(B, generator=g) > 0.4).float()
+    out.update(s2=np32(s2), mu2=np32(mu2), var2=np32(var2), mask_b=np32(mask_b),
+               d_full_dim1=np32(f(s2, mask_b, 1, mu=mu2, var=var2)),                  # [B]
+               d_std_dim1=np32(f(s2, mask_b, 1)),
+               d_novar_dimm1=np32(f(s2, mask_b, -1, mu=mu2, var=None)))               # dim=-1: mask [B] -> [B,1]
+    np.savez_compressed(os.path.join(OUT, "gll_generic.npz"), **out)
+    print("wrote gll_generic")
+
+
 def case_mmd(lo, seed, n, D, name):
     g = torch.Generator().manual_seed(seed)
     mu = torch.randn(n, D, generator=g)
@@ -384,6 +438,10 @@ def main():
         case_mi_generative(mi, "k64_v500", 26, 64, 500, False)
         case_mi_generative(mi, "k128_v600_peaked", 27, 128, 600, True)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-round2":
+        case_kde_batch(kde, 30)
+        case_gll_generic(mi, 31)
+        return
     case_logqz(lo, "generic", 0, 256, 256, 32, "generic")
     case_logqz(lo, "ragged", 1, 100, 77, 32, "generic")
     case_logqz(lo, "d64", 2, 128, 128, 64, "generic")
@@ -414,6 +472,8 @@ def main():
     case_mi_generative(mi, "k128_v600_peaked", 27, 128, 600, True)
     case_grad(lo, "d100", 28, 40, 56, 100)
     case_grad(lo, "d128", 29, 32, 32, 128)
+    case_kde_batch(kde, 30)
+    case_gll_generic(mi, 31)
 
 
 if __name__ == "__main__":

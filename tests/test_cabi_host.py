@@ -57,7 +57,7 @@ def test_argument_validation_and_error_text():
     assert rc == -1
     rc = lib.lvae_reparam_iw_f32(None, None, None, None, 4, 4, 32, None, None, None, None, None)
     assert rc == -1 and b"non-NULL" in lib.lvae_last_error()
-    rc = lib.lvae_kde_score_f32(None, None, 4, 4, 1, 1.0, 0, None, None, 0, None)
+    rc = lib.lvae_kde_score_f32(None, None, 4, 0, 4, 1, 1.0, 0, None, None, 0, None)
     assert rc == -1
     dummy = ctypes.c_void_p(256)
     arr = (ctypes.c_float * 2)(0.1, -1.0)
@@ -171,3 +171,33 @@ def test_committed_bench_line_has_the_contract_keys():
     assert c["kind"] in ("port", "reference") and c["unit"] == line["unit"]
     n = line["config"]["N"]
     assert abs(line["value"] - n * n / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+
+
+def test_mmd_workspace_queries_cover_the_layout_of_every_mode():
+    """The split search of the pair plan is monotone neither in the shape nor in `symmetric`, so a
+    *_workspace_bytes query must cover the extent of the layout each mode of its entry point really uses
+    (lvae_layout_info).  Includes the shapes on which the round-1 sizing fell short."""
+    from lvae import _native as N
+    lib = N.lib()
+    rng = np.random.default_rng(7)
+    shapes = [(22307, 92021, 8), (43846, 45790, 33), (18782, 185975, 128), (44842, 46005, 128)]
+    for _ in range(4000):
+        nb = int(rng.integers(2, 300000))
+        na = int(rng.integers(1, nb + 1))
+        shapes.append((na, nb, int(rng.integers(1, 257))))
+    info = (ctypes.c_int64 * 3)()
+    out = ctypes.c_int64(0)
+    for na, nb, D in shapes:
+        N.check(lib.lvae_kernel_sum_workspace_bytes(na, nb, D, out))
+        for sym in (0, 1):
+            N.check(lib.lvae_layout_info(0, na, nb, D, sym, info))
+            assert info[0] <= out.value, ("kernel_sum", na, nb, D, sym)
+        N.check(lib.lvae_mmd_perm_workspace_bytes(na, nb, D, out))
+        for sym in (0, 1):
+            N.check(lib.lvae_layout_info(1, na, nb, D, sym, info))
+            assert info[0] <= out.value, ("mmd_perm", na, nb, D, sym)
+        if na >= 2:
+            N.check(lib.lvae_mmd_workspace_bytes(na, nb, D, out))
+            for which in (0, 1, 2):
+                N.check(lib.lvae_layout_info(2, na, nb, D, which, info))
+                assert info[0] <= out.value, ("mmd_rbf", na, nb, D, which)

@@ -422,3 +422,38 @@ def test_mmd_wide_latents(n1, n2, D):
     got = float(E.maximum_mean_discrepancy(z, prior_sample=x))
     want = onp.maximum_mean_discrepancy(a, x.cpu().numpy())
     assert abs(got - want) <= 1e-4 * abs(want) + 1e-7
+
+
+def test_kde_batch_is_normalised_by_the_fit_size():
+    """score_samples(Y, X=batch) divides by the size of the FIT set (utils_latent_analysis_optimisation.py:58)."""
+    from lvae.kde import GaussianKDE
+    g = load_golden("kde_batch")
+    X, Y = dev(g["X"]), dev(g["Y"])
+    k = GaussianKDE(X=X, bw="scott")
+    assert abs(k.bw - float(g["bw"])) < 1e-12
+    close(k.score_samples(Y), g["score_full"], atol=1e-4)
+    close(k.score_samples(Y, X=X[:128]), g["score_batch_128"], atol=1e-4)
+    close(k.score_samples(Y, X=X[300:]), g["score_batch_tail"], atol=1e-4)
+    close(k.score_samples(Y, X=X[300:], stabilise=True), g["score_batch_tail"], atol=1e-4)
+    k2 = GaussianKDE(X=dev(g["X2"]), bw=0.4)
+    close(k2.score_samples(dev(g["Y2"]), X=dev(g["X2"])[:77]), g["score2_batch_77"], atol=1e-4)
+
+
+def test_gaussian_log_likelihood_generic_masks_and_axes():
+    """_gaussian_log_likelihood away from q_z_estimate's layout: real masks, other axes, 2-D samples
+    (mutual_information.py:26-41), against values the reference produced."""
+    from lvae import mutual_information as MI
+    g = load_golden("gll_generic")
+    f = MI._gaussian_log_likelihood
+    z3, mu, var = dev(g["z"]).unsqueeze(1), dev(g["mu"]), dev(g["var"])
+    msn, msd, mnd = dev(g["mask_sn"]), dev(g["mask_sd"]), dev(g["mask_nd"])
+    for got, key in ((f(z3, msn, 2, mu=mu, var=var), "a_full_dim2"), (f(z3, msn, 2, mu=None, var=var), "a_nomu_dim2"),
+                     (f(z3, msn, 2, mu=mu, var=None), "a_novar_dim2"), (f(z3, msn[:, :1], 2), "a_std_dim2"),
+                     (f(z3, msd, 1, mu=mu, var=var), "b_full_dim1"), (f(z3, mnd, 0, mu=mu, var=var), "c_full_dim0")):
+        assert tuple(got.shape) == g[key].shape, key
+        close(got, g[key], rtol=1e-4, atol=2e-3)
+    s2, mu2, var2, mb = dev(g["s2"]), dev(g["mu2"]), dev(g["var2"]), dev(g["mask_b"])
+    for got, key in ((f(s2, mb, 1, mu=mu2, var=var2), "d_full_dim1"), (f(s2, mb, 1), "d_std_dim1"),
+                     (f(s2, mb, -1, mu=mu2, var=None), "d_novar_dimm1")):
+        assert tuple(got.shape) == g[key].shape, key
+        close(got, g[key], rtol=1e-4, atol=1e-3)

@@ -188,3 +188,28 @@ def test_torch_eager_baseline(case):
                                 torch.from_numpy(g["z"]), math.log(g["mu"].shape[0]), True, row_chunk=50)
     close(lq.numpy(), g["log_q_z_all"], rtol=1e-5, atol=1e-4)
     close(pm.numpy(), g["log_q_z_prod_marg_all"], rtol=1e-5, atol=1e-4)
+
+
+def test_kde_batch_is_normalised_by_the_fit_size():
+    g = load_golden("kde_batch")
+    bw = float(g["bw"])
+    close(bw, onp.scott_bandwidth(512, 1), rtol=1e-12, atol=0)
+    close(onp.kde_score_samples(g["X"], g["Y"], bw), g["score_full"], atol=1e-5)
+    close(onp.kde_score_samples(g["X"][:128], g["Y"], bw, n_fit=512), g["score_batch_128"], atol=1e-5)
+    close(onp.kde_score_samples(g["X"][300:], g["Y"], bw, n_fit=512), g["score_batch_tail"], atol=1e-5)
+    close(onp.kde_score_samples(g["X2"][:77], g["Y2"], 0.4, n_fit=300), g["score2_batch_77"], atol=1e-5)
+
+
+def test_gaussian_log_likelihood_generic_masks_and_axes():
+    g = load_golden("gll_generic")
+    f = onp.gaussian_log_likelihood_masked
+    z3 = g["z"][:, None, :]
+    close(f(z3, g["mask_sn"], 2, g["mu"], g["var"]), g["a_full_dim2"], atol=2e-4)
+    close(f(z3, g["mask_sn"], 2, None, g["var"]), g["a_nomu_dim2"], atol=2e-4)
+    close(f(z3, g["mask_sn"], 2, g["mu"], None), g["a_novar_dim2"], atol=2e-4)
+    close(f(z3, g["mask_sn"][:, :1], 2), g["a_std_dim2"], atol=2e-4)
+    close(f(z3, g["mask_sd"], 1, g["mu"], g["var"]), g["b_full_dim1"], atol=5e-4)
+    close(f(z3, g["mask_nd"], 0, g["mu"], g["var"]), g["c_full_dim0"], atol=5e-4)
+    close(f(g["s2"], g["mask_b"], 1, g["mu2"], g["var2"]), g["d_full_dim1"], atol=2e-4)
+    close(f(g["s2"], g["mask_b"], 1), g["d_std_dim1"], atol=2e-4)
+    close(f(g["s2"], g["mask_b"], -1, g["mu2"], None), g["d_novar_dimm1"], atol=2e-4)
