@@ -69,6 +69,20 @@ int lvae_log_qz_f32(const float* z, const float* mu, const float* spread, int sp
                     float* log_qz, float* log_qz_prod_marg,
                     void* ws, int64_t ws_bytes, void* stream);
 
+/* The same computation as lvae_log_qz_f32 WITHOUT a workspace argument and without any allocation: no
+ * counterpart in the reference; for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  The scratch is a static device array inside the
+ * library, LVAE_NOALLOC_SCRATCH_BYTES (64 MiB) on every GPU the library runs on, held until the process ends;
+ * shapes whose plan needs more (lvae_log_qz_workspace_bytes) are rejected with LVAE_ERR_UNSUPPORTED -- e.g.
+ * M = N = 4,096 with prod-marginals or M = N = 32,768 without fit at D = 32.  The call issues no hipMalloc /
+ * hipFree (its first call on a device looks the array's address up once).  All calls on one GPU share that GPU's
+ * array: calls that overlap on one GPU (two streams, two threads) race; serialise them. */
+#define LVAE_NOALLOC_SCRATCH_BYTES (64u << 20)
+int lvae_log_qz_noalloc_f32(const float* z, const float* mu, const float* spread, int spread_kind,
+                            int64_t M, int64_t N, int D, float log_norm,
+                            int exclude_diag, int64_t diag_offset, int path,
+                            float* log_qz, float* log_qz_prod_marg, void* stream);
+
 /* Backward of lvae_log_qz_f32 (the reference differentiates approximate_log_q_z with autograd inside its
  * training objectives, loss_and_optimisation.py:925-1018 via modules/encoder.py:102-107).
  * Inputs: the forward inputs (logvar only), log_norm, the forward result log_qz [M] (needed with g_log_qz),

@@ -29,6 +29,8 @@ _SIGNATURES = {
     "lvae_log_qz_workspace_bytes": (_int, [_i64, _i64, _int, _int, ctypes.POINTER(_i64)]),
     "lvae_log_qz_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _int, _i64, _i64, _int, _f32, _int, _i64, _int,
                                _c_f32p, _c_f32p, ctypes.c_void_p, _i64, ctypes.c_void_p]),
+    "lvae_log_qz_noalloc_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _int, _i64, _i64, _int, _f32, _int, _i64, _int,
+                                       _c_f32p, _c_f32p, ctypes.c_void_p]),
     "lvae_log_qz_partial_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _int, _i64, _i64, _int, _int,
                                        _c_f32p, _c_f32p, ctypes.c_void_p, _i64, ctypes.c_void_p]),
     "lvae_qz_estimate_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _int, _i64, _i64, _int, _f32, _c_f32p,
@@ -96,6 +98,7 @@ _SIGNATURES = {
     "lvae_profile_end": (_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_int)]),
 }
 
+NOALLOC_SCRATCH_BYTES = 64 << 20
 REDUCE_WS_BYTES = 8192
 KMAT_WS_BYTES = 4096
 
@@ -142,7 +145,11 @@ def as_f32(t, name):
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
     if t.requires_grad:
-        raise LvaeError(f"{name} requires grad: the HIP path is forward-only (analysis path)")
+        # under torch.no_grad() the reference's plain torch ops just evaluate; with grad mode on, an estimator
+        # that reaches this point has no backward behind it (the differentiable ones detach first)
+        if torch.is_grad_enabled():
+            raise LvaeError(f"{name} requires grad: this estimator is forward-only (no HIP backward behind it)")
+        t = t.detach()
     if not t.is_cuda:
         raise LvaeError(f"{name} is on {t.device}: the HIP path needs a GPU tensor (no CPU fallback)")
     if t.dtype != torch.float32:

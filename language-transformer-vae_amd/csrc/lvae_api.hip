@@ -406,6 +406,56 @@ extern "C" int lvae_log_qz_f32(const float* z, const float* mu, const float* spr
                       log_qz, log_qz_prod_marg, nullptr, nullptr, ws, ws_bytes, (hipStream_t)stream);
 }
 
+// ---- allocation-free variant of lvae_log_qz_f32 -----------------------------------------------------------
+// For callers that cannot allocate device memory (HIP graph capture, serving loops, harnesses that forbid
+// hipMalloc): the workspace is this file-scope device array instead of a caller-provided buffer.  Every GPU the
+// library runs on holds its own copy at its own address until the process ends.  In host code the array's NAME
+// is only a stand-in for the symbol: the device address is looked up once per device (hipGetSymbolAddress with
+// that device current) and only that pointer is ever handed to kernels or memsets.
+static __device__ __align__(256) unsigned char scratch[LVAE_NOALLOC_SCRATCH_BYTES];
+#define LVAE_NOALLOC_MAX_DEVICES 64
+static void* g_scratch_ptr[LVAE_NOALLOC_MAX_DEVICES];     // device address of `scratch`, per device ordinal
+static std::mutex g_scratch_mu;
+
+static int scratch_of_current_device(void** out) {
+    int dev = -1;
+    LVAE_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= LVAE_NOALLOC_MAX_DEVICES)
+        return lvae_set_error(LVAE_ERR_UNSUPPORTED, "device ordinal %d outside 0..%d", dev, LVAE_NOALLOC_MAX_DEVICES - 1);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        LVAE_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return lvae_set_error(LVAE_ERR_HIP, "hipGetSymbolAddress returned a NULL address for the scratch array");
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return LVAE_OK;
+}
+
+extern "C" int lvae_log_qz_noalloc_f32(const float* z, const float* mu, const float* spread, int spread_kind,
+                                       int64_t M, int64_t N, int D, float log_norm, int exclude_diag,
+                                       int64_t diag_offset, int path, float* log_qz, float* log_qz_prod_marg,
+                                       void* stream) {
+    LVAE_CHECK_ARG(log_qz || log_qz_prod_marg, "at least one of log_qz / log_qz_prod_marg is required");
+    int rc = check_pair_shapes(z, mu, spread, spread_kind, M, N, D);
+    if (rc) return rc;
+    const PairPlan p = lvae_make_pair_plan(N, M, D, log_qz_prod_marg != nullptr);
+    if (p.total > (size_t)LVAE_NOALLOC_SCRATCH_BYTES)
+        return lvae_set_error(LVAE_ERR_UNSUPPORTED,
+                              "M=%lld, N=%lld, D=%d%s needs %zu bytes of scratch; the allocation-free entry point holds "
+                              "%zu per GPU (use lvae_log_qz_f32 with a caller-provided workspace)",
+                              (long long)M, (long long)N, D, log_qz_prod_marg ? " with prod-marginals" : "", p.total,
+                              (size_t)LVAE_NOALLOC_SCRATCH_BYTES);
+    void* ws = nullptr;
+    rc = scratch_of_current_device(&ws);
+    if (rc) return rc;
+    // run_log_qz clears what must start at zero (header, redo flags) at the start of every call; everything else
+    // in the workspace is written before it is read, so the previous call's contents do no harm.
+    return run_log_qz(z, mu, spread, spread_kind, M, N, D, log_norm, exclude_diag, diag_offset, path, log_qz,
+                      log_qz_prod_marg, nullptr, nullptr, ws, (int64_t)LVAE_NOALLOC_SCRATCH_BYTES, (hipStream_t)stream);
+}
+
 // ---- backward of the element-wise estimators -------------------------------------------------------------
 extern "C" int lvae_sample_ll_bwd_f32(const float* z, const float* mu, const float* logvar, int64_t B, int64_t K,
                                       int D, const float* g, int g_per_element, float* d_z, float* d_mu,

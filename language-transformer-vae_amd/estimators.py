@@ -1,8 +1,10 @@
 """Host-side mirror of the reference's latent estimators (NewsVAE/loss_and_optimisation.py).
 
 Same names, positional order, defaults and return shapes as the reference functions cited on each
-definition; the bodies call the HIP kernels through the C ABI (``_native``).  Forward-only: inputs that
-require grad are rejected.
+definition; the bodies call the HIP kernels through the C ABI (``_native``).  The estimators the reference
+differentiates in its training objectives (approximate_log_q_z, sample_log_likelihood, kl_divergence,
+reparameterisation; loss_and_optimisation.py:925-1018) carry HIP backward passes behind torch.autograd.Function;
+the others are forward-only and say so when handed inputs that require grad while grad mode is on.
 """
 import math
 
@@ -489,6 +491,8 @@ def approximate_marginal_KL(mu, logvar, latent_z, method="chen", dataset_size=No
     log_q_z, _ = approximate_log_q_z(mu, logvar, latent_z, method=method, dataset_size=dataset_size,
                                      prod_marginals=False, reduce_mean=False)
     log_p_z = sample_log_likelihood(latent_z, reduce_latent_dim=True, reduce_batch_dim=False)
+    if log_q_z.requires_grad or log_p_z.requires_grad:       # autograd outputs: torch's mean carries the graph
+        return log_q_z.mean() - log_p_z.mean()
     return N.mean_f32(log_q_z) - N.mean_f32(log_p_z)
 
 
