@@ -1,43 +1,125 @@
 #!/usr/bin/env python3
 """Benchmark of the latent-analysis hot path: the aggregate-posterior log q(z) matrix with its streaming
-logsumexp, reduced to marginal KL / MI (BASELINE.json configs[1]: N = M = 65,536, D = 32, one MI355X).
+logsumexp, reduced to marginal KL / MI.
 
-  python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W            (N > 1: starts its own N ranks, one per GPU)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (also fine)
+
+Workloads (`--workload`, default by --gpus):
+  c2    BASELINE configs[1]: N = M = 65,536, D = 32 on one MI355X -- the configuration the metric is quoted on;
+        the default at --gpus 1.
+  1m    the north star's multi-GPU shape: N = M = 1,048,576 posteriors / samples in total, rows sharded over the
+        ranks (STRONG scaling: the total is fixed); D = 32 for the metric, `--d 64` is BASELINE configs[2].
+        The default at --gpus > 1.
+  weak  N = M = 65,536 * sqrt(gpus): every GPU evaluates 65,536^2 pairs whatever the rank count.
+The one JSON line also carries the other multi-GPU mode as a nested object (`also_measured`), and at --gpus 1
+the single-GPU time of the 1m workload, so that the 1 -> 8 curve of the fixed-size job is on record.
 
 One "step" = one pass of the hot path over one batch of synthetic latents already resident in HBM:
-(N > 1: all-gather of the posterior parameters over RCCL) -> operand prep -> fused fp32-MFMA pair
-log-density + logsumexp -> per-sample log q(z|x), log p(z) -> float64 sums (N > 1: all-reduce) ->
-marginal KL and MI.  Multi-GPU runs are WEAK scaling: rows are sharded and N = M grows with sqrt(gpus)
-so that every GPU evaluates the same number of pairs (65,536^2) as the single-GPU run.
+(N > 1: all-gather of the posterior parameters over RCCL, hidden behind the rank's own block of the pair
+matrix) -> operand prep -> fused fp32-MFMA pair log-density + logsumexp -> per-sample log q(z|x), log p(z) ->
+float64 sums (N > 1: all-reduce) -> marginal KL and MI.
 
 Prints ONE JSON line (rank 0).  `value` is whole-job pair-evaluations per second.
 """
 import argparse
+import collections
+import importlib
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters (dense fp32 matrix)
 BASE_N = 65536
-D = 32
+NORTH_STAR_N = 1048576
 
 
-def problem_size(world):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=("auto", "c2", "1m", "weak"), default="auto")
+    ap.add_argument("--d", type=int, default=32, help="latent dimension (32: the metric; 64: BASELINE configs[2])")
+    ap.add_argument("--n", type=int, default=0, help="override N = M (development / tests; not a BASELINE workload)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-runs", action="store_true", help="skip the nested secondary measurements")
+    return ap.parse_args(argv)
+
+
+# ---- self-launch: one process per GPU ---------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher around it: start N fresh child processes (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment) and wait for them.  This parent never touches a GPU.  Rank 0's
+    stdout is this process's stdout; any rank failing fails the run (the others are stopped by their PIDs)."""
+    port = _free_port()
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LVAE_BENCH_CHILD="1")
+        out = None if rank == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
+    rc = 0
+    alive = set(range(len(procs)))
+    while alive:
+        for i in sorted(alive):
+            r = procs[i].poll()
+            if r is None:
+                continue
+            alive.discard(i)
+            if r != 0 and rc == 0:
+                rc = r
+                print(f"bench.py: rank {i} exited with status {r}; stopping the other ranks", file=sys.stderr, flush=True)
+                for j in alive:
+                    procs[j].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# ---- workloads ------------------------------------------------------------------------------------------------
+def weak_problem_size(world):
     """N = M so that N*M/world == BASE_N^2 (weak scaling), rounded to a multiple of 256*world."""
     q = 256 * world
     return max(q, int(round(BASE_N * math.sqrt(world) / q)) * q)
 
 
-def make_inputs(n_total, rank, world, device):
+def resolve_workload(args, world):
+    """-> (name, n_total, scaling, description)"""
+    name = args.workload
+    if name == "auto":
+        name = "c2" if world == 1 else "1m"
+    if args.n:
+        n = (args.n // world) * world
+        return "custom", n, "strong", f"custom N = M = {n} (development size, not a BASELINE workload)"
+    if name == "c2":
+        if world != 1:
+            raise SystemExit("workload c2 is the single-GPU configuration; use 1m or weak with --gpus > 1")
+        return name, BASE_N, "weak", ("BASELINE configs[1]: aggregate-posterior log q(z) matrix + logsumexp -> "
+                                      "marginal KL / MI, fused fp32 MFMA")
+    if name == "1m":
+        tag = "BASELINE configs[2]" if args.d == 64 else "north star 'scaling to 8 GPUs at N=1M' (configs[2] shape at the metric's D)"
+        return name, NORTH_STAR_N, "strong", (f"{tag}: marginal KL / MI at N = M = 1,048,576, D = {args.d}, rows "
+                                              f"sharded over {world} GPU(s), fixed total")
+    return name, weak_problem_size(world), "weak", ("BASELINE configs[1] per GPU: N = M = 65,536*sqrt(gpus), every GPU "
+                                                    "evaluates 65,536^2 pairs")
+
+
+def make_inputs(torch, n_total, D, rank, world, device):
     """SURVEY.md section 8(d) synthetic posteriors; every rank draws its own row block (seeded by rank)."""
     n_local = n_total // world
     g = torch.Generator(device=device).manual_seed(1234 + rank)
@@ -48,7 +130,7 @@ def make_inputs(n_total, rank, world, device):
     return mu, logvar, z
 
 
-def cpu_baseline(mu, logvar, z, log_norm, gpu_log_q_z, budget_s=12.0, max_rows=4096):
+def cpu_baseline(torch, mu, logvar, z, log_norm, gpu_log_q_z, D, budget_s=12.0, max_rows=4096):
     """Reference op chain (PyTorch eager, CPU) on a bounded row sample of the same workload."""
     from oracle import torch_eager
     threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
@@ -74,140 +156,210 @@ def cpu_baseline(mu, logvar, z, log_norm, gpu_log_q_z, budget_s=12.0, max_rows=4
             "parity_rel_mean_log_q_z": parity, "parity_max_abs": maxabs}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+class Bench:
+    """One rank of the benchmark."""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
-    # LVAE_BENCH_REHEARSAL=1: several ranks on one GPU, to rehearse the multi-rank code path on a
-    # single-GPU box (never used by the driver; numbers from it mean nothing)
-    rehearsal = os.environ.get("LVAE_BENCH_REHEARSAL") == "1"
-    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    if world > 1:
-        if rehearsal:
-            dist.init_process_group("gloo")
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.args = torch, dist, args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        # LVAE_BENCH_REHEARSAL=1: several ranks on ONE GPU with gloo, to rehearse the multi-rank code path on a
+        # single-GPU box.  LVAE_BENCH_KERNELS=<module>: test hook -- the per-rank compute comes from the named module
+        # (`local_stats`, `BlockKernels`) and everything runs on the CPU over gloo: the CPU test suite uses it to
+        # exercise launch, sharding, exchange and reporting without a GPU.  Numbers from either mean nothing.
+        self.kernels_mod = os.environ.get("LVAE_BENCH_KERNELS") or None
+        self.rehearsal = os.environ.get("LVAE_BENCH_REHEARSAL") == "1" or self.kernels_mod is not None
+        if self.kernels_mod:
+            self.device = torch.device("cpu")
         else:
-            dist.init_process_group("nccl", device_id=device)
+            ndev = torch.cuda.device_count()
+            if ndev < 1:
+                raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+            if not self.rehearsal and local_rank >= ndev:
+                raise SystemExit(f"rank {local_rank} has no GPU ({ndev} visible)")
+            idx = local_rank % ndev
+            torch.cuda.set_device(idx)
+            self.device = torch.device("cuda", idx)
+        if self.world > 1:
+            if self.rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=self.device)
+        from lvae import distributed as LD
+        self.LD = LD
+        self.local_stats, self.block_kernels = LD.hip_local_stats, LD.HipBlockKernels
+        if self.kernels_mod:
+            mod = importlib.import_module(self.kernels_mod)
+            self.local_stats, self.block_kernels = mod.local_stats, mod.BlockKernels
+        self.gpu = self.device.type == "cuda"
 
-    from lvae import _native as N
-    from lvae import distributed as LD
-    from lvae import estimators as E
+    def sync(self):
+        if self.gpu:
+            self.torch.cuda.synchronize()
 
-    n_total = problem_size(world)
-    mu, logvar, z = make_inputs(n_total, rank, world, device)
-    log_norm = math.log(n_total)
-    state = {}
+    def fence(self):
+        self.sync()
+        if self.world > 1:
+            self.dist.barrier()
+        self.sync()
 
-    exchange = {"overlap": None, "note": "all-gather overlapped with the own-posterior block"}
+    def measure(self, n_total, D, steps, warmup, ramp):
+        """`ramp` + `warmup` untimed steps, then exactly `steps` timed ones between two fences; returns a dict with
+        the max-over-ranks elapsed time, the pair kernel's summed HIP-event time and the statistics of the last step."""
+        torch, dist, LD, world = self.torch, self.dist, self.LD, self.world
+        mu, logvar, z = make_inputs(torch, n_total, D, self.rank, world, self.device)
+        log_norm = math.log(n_total)
+        # Every step's device results AND the handle of its asynchronous all-reduce are held until the handle has
+        # been waited on; a step retires the one from two steps back (long complete: the wait costs nothing and
+        # the compute stream never stalls behind the newest collective).
+        pending = collections.deque()
 
-    # One step = the whole job once: exchange (N > 1), operand prep, pair kernel, merge, the five float64 sums,
-    # all-reduce (N > 1).  The sums stay on the device; the host reads them once after the timed steps (a step
-    # never waits on the host, so the device runs them back to back, like consecutive evaluation batches).
-    def step():
-        if world > 1:
-            state["dev"] = LD.sharded_latent_sums(mu, logvar, z, method="all", counts=[n_total // world] * world,
-                                                  overlap=exchange["overlap"], async_reduce=True)
-        else:
-            sums, lq = LD.hip_local_stats(mu, logvar, z, mu, logvar, log_norm, False)
-            state["dev"] = (sums, lq, n_total, None)
+        def retire(entry):
+            if entry[3] is not None:
+                entry[3].wait()
+            return entry
 
-    def read_out():
-        sums, lq, n, work = state["dev"]
-        if work is not None:
-            work.wait()
-        state["out"] = LD.stats_from_sums(sums, n, lq)
+        def step():
+            if world > 1:
+                cur = LD.sharded_latent_sums(mu, logvar, z, method="all", counts=[n_total // world] * world,
+                                             local_stats=self.local_stats, block_kernels=self.block_kernels,
+                                             async_reduce=True)
+            else:
+                sums, lq = self.local_stats(mu, logvar, z, mu, logvar, log_norm, False)
+                cur = (sums, lq, n_total, None)
+            pending.append(cur)
+            while len(pending) > 2:
+                retire(pending.popleft())
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # Untimed prelude before the W warm-up steps: the GPU clock needs ~8 launches (35 ms) of this kernel to ramp
-    # from idle (4.8 ms for the first launch, 4.04 ms in steady state); reported as "clock_ramp_steps".
-    RAMP = 10
-    if world > 1:
-        # the overlapped exchange has only been rehearsed on one GPU (gloo); if its first call fails here for a
-        # reason every rank sees alike, fall back to gather-then-compute rather than lose the measurement
-        try:
+        # Untimed prelude before the W warm-up steps: the GPU clock needs ~8 launches (35 ms) of the 65,536^2 kernel
+        # to ramp from idle (4.8 ms for the first launch, 4.04 ms in steady state); reported as "clock_ramp_steps".
+        # A failure of the (overlapped) exchange in any step is fatal: the exception ends this rank with a non-zero
+        # status and the launcher stops the others -- there is no fallback path.
+        for _ in range(ramp + warmup):
             step()
-            torch.cuda.synchronize()
-        except Exception as e:                     # noqa: BLE001
-            exchange.update(overlap=False, note="blocking all-gather (overlapped exchange failed: %r)" % (e,))
+        self.fence()
+        prof = None
+        if self.gpu:
+            import ctypes
+            from lvae import _native as N
+            N.check(N.lib().lvae_profile_begin(4 * steps))   # (the overlapped multi-GPU step launches the pair kernel twice)
+            prof = (ctypes, N)
+        t0 = time.perf_counter()
+        for _ in range(steps):
             step()
-    for _ in range(RAMP):
-        step()
-    for _ in range(args.warmup):
-        step()
-    fence()
-    N.check(N.lib().lvae_profile_begin(4 * args.steps))    # (the overlapped multi-GPU step launches the pair kernel twice)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    read_out()
-    import ctypes
-    k_ms, k_n = ctypes.c_double(0), ctypes.c_int(0)
-    N.check(N.lib().lvae_profile_end(ctypes.byref(k_ms), ctypes.byref(k_n)))
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        last = None
+        while pending:
+            last = retire(pending.popleft())
+        self.sync()
+        k_ms, k_n = 0.0, 0
+        if prof:
+            ctypes, N = prof
+            a, b = ctypes.c_double(0), ctypes.c_int(0)
+            N.check(N.lib().lvae_profile_end(ctypes.byref(a), ctypes.byref(b)))
+            k_ms, k_n = a.value, b.value
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if self.rehearsal else self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        out = LD.stats_from_sums(last[0], last[2], last[1])
+        return {"elapsed": elapsed, "k_ms": k_ms, "k_n": k_n, "out": out, "inputs": (mu, logvar, z), "log_norm": log_norm}
 
-    if rank == 0:
+    def summary(self, m, n_total, D, steps):
+        """value / ms_per_step / roofline numbers of one measurement."""
         pairs_total = float(n_total) * float(n_total)
-        ms_per_step = elapsed / args.steps * 1e3
-        value = pairs_total * args.steps / elapsed
-        pairs_rank = pairs_total / world
-        # pair-kernel time per step: one launch at N=1; with more ranks the step launches it twice (own block of
-        # posteriors while the all-gather runs, then the others), and the two durations are added
-        k_avg_ms = k_ms.value / args.steps
-        achieved = 4.0 * D * pairs_rank / (k_avg_ms * 1e-3) / 1e12 if k_n.value else None
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and world == 1:
-            with open(tpath) as f:
-                traffic = json.load(f).get("pair_lse_mfma_kernel_hbm_bytes_per_launch")
-        line = {
-            "metric": "log q(z|x) pair-evals/sec at D=32", "value": value, "unit": "pair-evals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_ramp_steps": RAMP,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: aggregate-posterior log q(z) matrix + logsumexp "
-                                   "-> marginal KL / MI, fused fp32 MFMA",
-                       "N": n_total, "M": n_total, "D": D, "pairs_per_gpu": pairs_rank,
-                       "parallelism": f"row-sharded x{world}, all-gather(mu,logvar)+all-reduce(sums)",
-                       "exchange": exchange["note"] if world > 1 else "none"},
-            "pct_of_fp32_mfma_peak": value * 4 * D / (world * FP32_MFMA_PEAK_TFLOPS * 1e12) * 100.0,
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s",
-                         "frac": (achieved / FP32_MFMA_PEAK_TFLOPS) if achieved else None,
-                         "traffic": traffic, "kernel": "pair_lse_mfma_kernel<32,2,2,false,4> (fixed-reference logsumexp epilogue)",
-                         "kernel_ms_avg": k_avg_ms, "launches": k_n.value,
-                         "launches_per_step": k_n.value / args.steps,
-                         "flops_per_launch": 4.0 * D * pairs_rank * args.steps / max(k_n.value, 1)},
-            "result_read": "device-resident sums, read by the host once after the timed steps",
-            "results": {k: v for k, v in state["out"].items() if isinstance(v, float)},
-        }
-        if world == 1:
+        pairs_rank = pairs_total / self.world
+        k_avg_ms = m["k_ms"] / steps
+        achieved = 4.0 * D * pairs_rank / (k_avg_ms * 1e-3) / 1e12 if m["k_n"] else None
+        value = pairs_total * steps / m["elapsed"]
+        return {"value": value, "ms_per_step": m["elapsed"] / steps * 1e3, "pairs_rank": pairs_rank,
+                "k_avg_ms": k_avg_ms, "achieved": achieved,
+                "pct_of_peak": value * 4 * D / (self.world * FP32_MFMA_PEAK_TFLOPS * 1e12) * 100.0}
+
+    def run(self):
+        args, world, rank, torch = self.args, self.world, self.rank, self.torch
+        D = args.d
+        name, n_total, scaling, desc = resolve_workload(args, world)
+        long_step = float(n_total) ** 2 / world > 4.0 * BASE_N ** 2
+        ramp = 2 if long_step else 10
+        m = self.measure(n_total, D, args.steps, args.warmup, ramp)
+        s = self.summary(m, n_total, D, args.steps)
+        line = None
+        if rank == 0:
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath) and world == 1 and name == "c2" and D == 32:
+                with open(tpath) as f:
+                    traffic = json.load(f).get("pair_lse_mfma_kernel_hbm_bytes_per_launch")
+            n_r = n_total // world
+            line = {
+                "metric": "log q(z|x) pair-evals/sec at D=32" if D == 32 else f"log q(z|x) pair-evals/sec at D={D}",
+                "value": s["value"], "unit": "pair-evals/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_ramp_steps": ramp,
+                "ms_per_step": s["ms_per_step"],
+                "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic",
+                "config": {"workload": desc, "name": name,
+                           "N": n_total, "M": n_total, "D": D, "pairs_per_gpu": s["pairs_rank"],
+                           "rows_per_gpu": n_r,
+                           "parallelism": f"row-sharded x{world}, all-gather(mu,logvar)+all-reduce(sums)",
+                           "exchange": ("all-gather of %d x [%d, %d] fp32 = %.1f MB per rank, overlapped with the "
+                                        "own-posterior block; async all-reduce of 5 float64 sums"
+                                        % (world, n_r, 2 * D, world * n_r * 2 * D * 4 / 1e6)) if world > 1 else "none"},
+                "pct_of_fp32_mfma_peak": s["pct_of_peak"],
+                "roofline": {"bound": "mfma", "achieved": s["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS,
+                             "unit": "TFLOP/s",
+                             "frac": (s["achieved"] / FP32_MFMA_PEAK_TFLOPS) if s["achieved"] else None,
+                             "traffic": traffic,
+                             "kernel": "pair_lse_mfma_kernel (fp32 MFMA contraction, fixed-reference logsumexp epilogue)",
+                             "kernel_ms_avg": s["k_avg_ms"], "launches": m["k_n"],
+                             "launches_per_step": m["k_n"] / args.steps,
+                             "flops_per_launch": 4.0 * D * s["pairs_rank"] * args.steps / max(m["k_n"], 1)},
+                "result_read": "device-resident sums, read by the host once after the timed steps",
+                "results": {k: v for k, v in m["out"].items() if isinstance(v, float)},
+            }
+            if self.rehearsal:
+                line["rehearsal"] = "several ranks on one device / injected per-rank compute: the numbers mean nothing"
+        # ---- secondary measurements, nested in the same line (every rank takes part in the collective ones) ----
+        if not args.no_side_runs and not args.n:
+            side = {}
+            if world > 1:
+                other = "weak" if name == "1m" else "1m"
+                n2 = weak_problem_size(world) if other == "weak" else NORTH_STAR_N
+                st2 = max(3, min(args.steps, 20 if other == "weak" else 5))
+                m2 = self.measure(n2, D, st2, 2, 2)
+                s2 = self.summary(m2, n2, D, st2)
+                side[other] = {"N": n2, "value": s2["value"], "unit": "pair-evals/s", "ms_per_step": s2["ms_per_step"],
+                               "steps": st2, "scaling": "weak" if other == "weak" else "strong",
+                               "pct_of_fp32_mfma_peak": s2["pct_of_peak"], "kernel_ms_avg": s2["k_avg_ms"]}
+            elif name == "c2" and self.gpu:
+                # the fixed-size multi-GPU job on ONE GPU: the base point of its strong-scaling curve
+                st2 = 2
+                m2 = self.measure(NORTH_STAR_N, D, st2, 1, 0)
+                s2 = self.summary(m2, NORTH_STAR_N, D, st2)
+                side["1m"] = {"N": NORTH_STAR_N, "value": s2["value"], "unit": "pair-evals/s",
+                              "ms_per_step": s2["ms_per_step"], "steps": st2, "scaling": "strong",
+                              "pct_of_fp32_mfma_peak": s2["pct_of_peak"], "kernel_ms_avg": s2["k_avg_ms"],
+                              "marginal_kl": m2["out"]["marginal_kl"], "mi": m2["out"]["mi"]}
+                del m2
+            if rank == 0:
+                line["also_measured"] = side
+        if rank == 0 and world == 1 and self.gpu and name == "c2":
+            from lvae import _native as N
+            mu, logvar, z = m["inputs"]
+            log_norm = m["log_norm"]
+            pairs_total = float(n_total) ** 2
             # Not the headline: the same step with the pair kernel swapped for the opt-in split-bf16 one
             # (LVAE_PATH_MFMA_BF16X3: three bf16 limbs per fp32 value on the bf16 matrix pipe, fp32-equivalent
             # results), timed after the headline measurement.  `value` above stays the fp32 MFMA path.
             def step_bx():
-                sums, _ = LD.hip_local_stats(mu, logvar, z, mu, logvar, log_norm, False, path=N.PATH_MFMA_BF16X3)
+                sums, _ = self.LD.hip_local_stats(mu, logvar, z, mu, logvar, log_norm, False, path=N.PATH_MFMA_BF16X3)
                 return sums                   # read after the loop, like the headline step
             try:
                 for _ in range(2):
@@ -222,17 +374,28 @@ def main():
                 line["experimental_bf16x3"] = {
                     "value": pairs_total * args.steps / el, "unit": "pair-evals/s",
                     "ms_per_step": el / args.steps * 1e3, "marginal_kl": (s_lq - s_lp) / cnt,
-                    "rel_diff_marginal_kl_vs_fp32_path": abs((s_lq - s_lp) / cnt - state["out"]["marginal_kl"])
-                    / abs(state["out"]["marginal_kl"]),
+                    "rel_diff_marginal_kl_vs_fp32_path": abs((s_lq - s_lp) / cnt - m["out"]["marginal_kl"])
+                    / abs(m["out"]["marginal_kl"]),
                     "note": "opt-in path, not the north star's fp32 MFMA contraction; see DESIGN.md"}
             except Exception as e:                       # never lose the headline line over the side measurement
                 line["experimental_bf16x3"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(mu, logvar, z, log_norm, state["out"]["log_q_z_local"])
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(torch, mu, logvar, z, log_norm, m["out"]["log_q_z_local"], D)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    Bench(args).run()
 
 
 if __name__ == "__main__":

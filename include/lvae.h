@@ -148,6 +148,13 @@ int lvae_lse_combine_f32(const float* max_a, const float* sum_a, const float* ma
                          int64_t n, float log_norm, float* out_log_qz, float* out_max, float* out_sum,
                          void* stream);
 
+/* The all-reduce form of the same merge (column-sharded posteriors): once the owners have
+ * all-reduced their row_max into new_max (>= max_a), out_sum = sum_a * exp(max_a - new_max) re-expresses this
+ * owner's sums against it, so that all-reduce(sum) of out_sum followed by lvae_lse_combine_f32(new_max, sum, NULL,
+ * NULL, ..) finishes log_qz.  out_sum may alias sum_a.  No counterpart in the reference. */
+int lvae_lse_rebase_f32(const float* max_a, const float* sum_a, const float* new_max, int64_t n, float* out_sum,
+                        void* stream);
+
 /* q_z_estimate (mutual_information.py:44-52) including quirk Q2: the reduction runs over the SAMPLE
  * axis:  out[j] = LSE_i log N(z_i; mu_j, var_j) - log_norm,  out [N].  Workspace: query with the
  * roles swapped, lvae_log_qz_workspace_bytes(N, M, D, 0, ..). */

@@ -57,6 +57,7 @@ _SIGNATURES = {
                                  ctypes.c_void_p]),
     "lvae_lse_combine_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _f32, _c_f32p, _c_f32p, _c_f32p,
                                     ctypes.c_void_p]),
+    "lvae_lse_rebase_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, ctypes.c_void_p]),
     "lvae_set_pair_math": (_int, [_int]),
     "lvae_get_pair_math": (_int, []),
     "lvae_log_prob_pairs_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _int, _i64, _i64, _int, _c_f32p,

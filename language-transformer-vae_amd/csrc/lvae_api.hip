@@ -104,6 +104,8 @@ int lvae_launch_kl_bwd(const float* mu, const float* logvar, const float* g_kl, 
                        hipStream_t st);
 int lvae_launch_lse_combine(const float* max_a, const float* sum_a, const float* max_b, const float* sum_b,
                             int64_t n, float log_norm, float* out, float* out_max, float* out_sum, hipStream_t st);
+int lvae_launch_lse_rebase(const float* max_a, const float* sum_a, const float* new_max, int64_t n, float* out_sum,
+                           hipStream_t st);
 int lvae_launch_grad_wide(const float* z, const float* dparams, const float* P, const float* log_qz, float log_norm,
                           const float* g, const float* h, const float* lse2, int64_t M, int64_t N, int D, int DC,
                           float* d_z, float* d_mu, float* d_logvar, hipStream_t st);
@@ -623,6 +625,13 @@ extern "C" int lvae_lse_combine_f32(const float* max_a, const float* sum_a, cons
     LVAE_CHECK_ARG(n >= 1, "need n >= 1");
     return lvae_launch_lse_combine(max_a, sum_a, max_b, sum_b, n, log_norm, out_log_qz, out_max, out_sum,
                                    (hipStream_t)stream);
+}
+
+extern "C" int lvae_lse_rebase_f32(const float* max_a, const float* sum_a, const float* new_max, int64_t n,
+                                   float* out_sum, void* stream) {
+    LVAE_CHECK_ARG(max_a && sum_a && new_max && out_sum, "NULL pointer");
+    LVAE_CHECK_ARG(n >= 1, "need n >= 1");
+    return lvae_launch_lse_rebase(max_a, sum_a, new_max, n, out_sum, (hipStream_t)stream);
 }
 
 // Roles swapped: posteriors on the kept axis (one output each), samples on the reduced axis.

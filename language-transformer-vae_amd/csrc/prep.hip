@@ -513,6 +513,24 @@ lse_combine_kernel(const float* max_a, const float* sum_a, const float* max_b, c
     }
 }
 
+// (max_a, sum_a) re-expressed against a new, not smaller reference: out_sum = sum_a * exp(max_a - new_max), so that
+// the sums of several owners add up (all-reduce) once they share the all-reduced maximum.
+__global__ void __launch_bounds__(256)
+lse_rebase_kernel(const float* max_a, const float* sum_a, const float* new_max, int64_t n, float* out_sum) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float s = sum_a[i];
+    out_sum[i] = s > 0.f ? (float)((double)s * exp((double)max_a[i] - (double)new_max[i])) : 0.f;
+}
+
+int lvae_launch_lse_rebase(const float* max_a, const float* sum_a, const float* new_max, int64_t n, float* out_sum,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(lse_rebase_kernel, dim3((unsigned)lvae_ceil_div(n, 256)), dim3(256), 0, st, max_a, sum_a,
+                       new_max, n, out_sum);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
 int lvae_launch_lse_combine(const float* max_a, const float* sum_a, const float* max_b, const float* sum_b,
                             int64_t n, float log_norm, float* out, float* out_max, float* out_sum, hipStream_t st) {
     hipLaunchKernelGGL(lse_combine_kernel, dim3((unsigned)lvae_ceil_div(n, 256)), dim3(256), 0, st, max_a, sum_a,

@@ -329,11 +329,34 @@ def sharded_mmd_permutation_test(x_local, y_local, alphas, labels, dist_eps=1e-5
             "pval": float((stats[1:] >= stats[0]).double().mean()) if P > 1 else float("nan")}
 
 
-def combine_partial_lse(row_max, row_sum, log_norm, group=None):
+class HipLseKernels:
+    """Device steps of ``combine_partial_lse`` on the HIP path (lvae_lse_rebase_f32, lvae_lse_combine_f32); the CPU
+    tests inject an oracle-backed object with the same two methods."""
+
+    @staticmethod
+    def rebase(row_max, row_sum, new_max):
+        from . import _native as N
+        m, s, g = (N.as_f32(t, "partial") for t in (row_max, row_sum, new_max))
+        dev = m.device
+        with torch.cuda.device(dev):
+            out = torch.empty_like(s)
+            N.check(N.lib().lvae_lse_rebase_f32(N.ptr(m), N.ptr(s), N.ptr(g), m.numel(), N.ptr(out),
+                                                N.stream_ptr(dev)))
+        return out
+
+    @staticmethod
+    def finish(gmax, gsum, log_norm):
+        from . import estimators as E
+        return E.lse_combine((gmax, gsum), None, log_norm)
+
+
+def combine_partial_lse(row_max, row_sum, log_norm, group=None, kernels=HipLseKernels):
     """Column-sharded alternative: every rank holds ALL z rows but only its posteriors and has produced
-    (row_max, row_sum) with lvae_log_qz_partial_f32.  all-reduce(max), rescale, all-reduce(sum)."""
+    (row_max, row_sum) with lvae_log_qz_partial_f32.  all-reduce(max); the sums re-expressed against the common
+    maximum on the device (lvae_lse_rebase_f32); all-reduce(sum); log q(z) finished on the device
+    (lvae_lse_combine_f32)."""
     gmax = row_max.clone()
     _all_reduce(gmax, dist.ReduceOp.MAX, group)
-    scaled = row_sum.double() * torch.exp(row_max.double() - gmax.double())
+    scaled = kernels.rebase(row_max, row_sum, gmax)
     _all_reduce(scaled, dist.ReduceOp.SUM, group)
-    return (gmax.double() + torch.log(scaled) - log_norm).float()
+    return kernels.finish(gmax, scaled, log_norm)

@@ -38,6 +38,18 @@ def _oracle_local_stats(mu_all, logvar_all, z_local, mu_local, logvar_local, log
     return sums, torch.from_numpy(lq)
 
 
+class _OracleLseKernels:
+    """CPU stand-in for distributed.HipLseKernels (float64 arithmetic, float32 storage like the device steps)."""
+
+    @staticmethod
+    def rebase(row_max, row_sum, new_max):
+        return (row_sum.double() * torch.exp(row_max.double() - new_max.double())).float()
+
+    @staticmethod
+    def finish(gmax, gsum, log_norm):
+        return (gmax.double() + torch.log(gsum.double()) - log_norm).float()
+
+
 def _worker(rank, world, port, n, D, ragged, q):
     import sys
     sys.path.insert(0, ROOT)
@@ -60,7 +72,8 @@ def _worker(rank, world, port, n, D, ragged, q):
     dens = onp.log_prob_pairs(z, mu[lo:hi], np.exp(lv[lo:hi].astype(np.float64)))     # [cols, rows]
     rmax = dens.max(0)
     rsum = np.exp(dens - rmax[None]).sum(0)
-    comb = LD.combine_partial_lse(torch.from_numpy(rmax).float(), torch.from_numpy(rsum).float(), math.log(n))
+    comb = LD.combine_partial_lse(torch.from_numpy(rmax).float(), torch.from_numpy(rsum).float(), math.log(n),
+                                  kernels=_OracleLseKernels)
     # ragged all-gather
     gathered, offs = LD.all_gather_rows(torch.from_numpy(mu[lo:hi].copy()))
     ok_gather = bool(torch.equal(gathered, torch.from_numpy(mu))) and offs[-1] == n

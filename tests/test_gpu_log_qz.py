@@ -290,6 +290,14 @@ def test_partial_logsumexp_blocks_merge_to_the_full_result():
     rest = E.log_qz_partial(dev(mu[275:]), dev(logvar[275:]), dev(z))
     two = E.lse_combine(own, rest, np.log(N_))
     np.testing.assert_allclose(two.cpu().numpy(), ref, rtol=1e-4, atol=1e-3)
+    # all-reduce form of the column-sharded variant (distributed.combine_partial_lse): max over the owners, every
+    # owner's sums re-expressed against it on the device (lvae_lse_rebase_f32), summed, finished on the device
+    from lvae.distributed import HipLseKernels as LK
+    parts = [E.log_qz_partial(dev(mu[lo:hi]), dev(logvar[lo:hi]), dev(z)) for lo, hi in ((0, 400), (400, 700), (700, 1100))]
+    gmax = torch.stack([p_[0] for p_ in parts]).max(0).values              # what all-reduce(MAX) leaves on every rank
+    gsum = sum(LK.rebase(p_[0], p_[1], gmax) for p_ in parts)               # what all-reduce(SUM) leaves
+    three = LK.finish(gmax, gsum, np.log(N_))
+    np.testing.assert_allclose(three.cpu().numpy(), ref, rtol=1e-4, atol=1e-3)
 
 
 @pytest.mark.parametrize("n_base,reps,D,M_", [(4096, 256, 64, 384),        # N = 1,048,576, D = 64: C3's posterior count
