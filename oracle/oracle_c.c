@@ -60,6 +60,35 @@ void oracle_log_qz(const float* z, const float* mu, const float* logvar, int64_t
     free(base);
 }
 
+/* logsumexp_j over j != i + diag_offset of sum_d log_dens[i][j][d], minus log_norm: the masked logsumexp of
+ * mi_upper_bound (NewsVAE/mutual_information.py:204-213, the diagonal set to -inf at :207). */
+void oracle_log_qz_excl(const float* z, const float* mu, const float* logvar, int64_t M, int64_t N, int D,
+                        double log_norm, int64_t diag_offset, double* out) {
+    double* inv_var = (double*)malloc(sizeof(double) * (size_t)N * D);
+    double* base = (double*)malloc(sizeof(double) * (size_t)N * D);
+    for (int64_t k = 0; k < N * D; ++k) {
+        inv_var[k] = exp(-(double)logvar[k]);
+        base[k] = -0.5 * ((double)logvar[k] + LOG_2PI);
+    }
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t i = 0; i < M; ++i) {
+        double mj = -INFINITY, sj = 0.0;
+        for (int64_t j = 0; j < N; ++j) {
+            if (j == i + diag_offset) continue;
+            double v = 0.0;
+            for (int d = 0; d < D; ++d) {
+                const double diff = (double)z[i * D + d] - (double)mu[j * D + d];
+                v += base[j * D + d] - 0.5 * diff * diff * inv_var[j * D + d];
+            }
+            if (v > mj) { sj = sj * exp(mj - v) + 1.0; mj = v; }
+            else sj += exp(v - mj);
+        }
+        out[i] = mj + log(sj) - log_norm;
+    }
+    free(inv_var);
+    free(base);
+}
+
 /* z = mu + eps*std in float32 like the reference (encoder.py:149,157); densities and the
  * importance-weighted logsumexp in double.  Any output pointer may be NULL. */
 void oracle_reparam_iw(const float* mu, const float* logvar, const float* eps, const float* log_p_x_z,

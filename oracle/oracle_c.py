@@ -36,6 +36,20 @@ def log_qz(z, mu, logvar, log_norm, prod_marginals=True):
     return lq, pm
 
 
+def log_qz_excl(z, mu, logvar, log_norm, diag_offset=0):
+    """logsumexp over the posteriors j != i + diag_offset (mi_upper_bound's masked logsumexp)."""
+    z, mu, logvar = (np.ascontiguousarray(a, dtype=np.float32) for a in (z, mu, logvar))
+    M, D = z.shape
+    N = mu.shape[0]
+    out = np.empty(M, dtype=np.float64)
+    f = lib().oracle_log_qz_excl
+    f.restype = None
+    f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
+                                          ctypes.c_int64, ctypes.c_void_p]
+    f(_p(z), _p(mu), _p(logvar), M, N, D, float(log_norm), int(diag_offset), _p(out))
+    return out
+
+
 def reparam_iw(mu, logvar, eps, log_p_x_z=None):
     mu, logvar, eps = (np.ascontiguousarray(a, dtype=np.float32) for a in (mu, logvar, eps))
     B, K, D = eps.shape

@@ -213,3 +213,20 @@ def test_gaussian_log_likelihood_generic_masks_and_axes():
     close(f(g["s2"], g["mask_b"], 1, g["mu2"], g["var2"]), g["d_full_dim1"], atol=2e-4)
     close(f(g["s2"], g["mask_b"], 1), g["d_std_dim1"], atol=2e-4)
     close(f(g["s2"], g["mask_b"], -1, g["mu2"], None), g["d_novar_dimm1"], atol=2e-4)
+
+
+def test_c_oracle_masked_logsumexp_reproduces_the_golden_upper_bound():
+    """oracle_c.log_qz_excl (used by the K = 20,000 GPU test) against the reference's MBU bound (quirk Q3:
+    variance = std, i.e. "logvar" = 0.5 * logvar)."""
+    from oracle import oracle_c
+    import math
+    g = load_golden("mi_bounds_k128")
+    z, mulv = g["z"], g["mu_logvars"]
+    D = mulv.shape[1] // 2
+    mu, lv = mulv[:, :D], mulv[:, D:]
+    K = len(z)
+    diag = onp.sample_log_likelihood(z, mu, 0.5 * lv, reduce_batch_dim=False)
+    off = oracle_c.log_qz_excl(z, mu, 0.5 * lv, 0.0, 0)
+    allj, _ = oracle_c.log_qz(z, mu, 0.5 * lv, 0.0, False)
+    close(np.mean(diag - (off - math.log(K - 1))), g["upper"], rtol=1e-5, atol=1e-5)
+    close(np.mean(diag - (allj - math.log(K))), g["lower"], rtol=1e-5, atol=1e-5)
