@@ -196,6 +196,15 @@ int lvae_iw_lse_f32(const float* log_p_x_z, const float* log_p_z, const float* l
 int lvae_latent_sums_f32(const float* z, const float* mu, const float* logvar, const float* log_qz,
                          const float* log_qz_prod_marg, int64_t M, int D, double* sums, void* stream);
 
+/* lvae_log_qz_f32 (joint density, logvar parameterisation) followed by lvae_latent_sums_f32 as ONE call: log_qz
+ * [M] and sums[5] for samples z_i drawn from posterior (mu_local[i], logvar_local[i]) (this rank's rows of the
+ * N posteriors), i.e. everything the consumer lines loss_and_optimisation.py:816-824 need for marginal KL and MI.
+ * On small problems (N * M <= 2^26) the statistics ride on the kernel that merges the split partials.
+ * Workspace: lvae_log_qz_workspace_bytes(M, N, D, 0, ..). */
+int lvae_latent_stats_f32(const float* z, const float* mu_all, const float* logvar_all, int64_t M, int64_t N, int D,
+                          float log_norm, int path, const float* mu_local, const float* logvar_local, float* log_qz,
+                          double* sums, void* ws, int64_t ws_bytes, void* stream);
+
 /* Deterministic reduction to one float64 in device memory: mode 0: scale*sum(x), mode 1:
  * scale*sum(exp(x)).  Used for the `.mean()` the reference applies to per-sample vectors
  * (loss_and_optimisation.py:108,:217-219).  Workspace: LVAE_REDUCE_WS_BYTES. */

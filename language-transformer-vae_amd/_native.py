@@ -46,6 +46,8 @@ _SIGNATURES = {
                                _i64, ctypes.c_void_p]),
     "lvae_latent_sums_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _int, ctypes.c_void_p,
                                     ctypes.c_void_p]),
+    "lvae_latent_stats_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _i64, _int, _f32, _int, _c_f32p, _c_f32p,
+                                     _c_f32p, ctypes.c_void_p, ctypes.c_void_p, _i64, ctypes.c_void_p]),
     "lvae_pair_bounds_workspace_bytes": (_int, [_i64, _int, ctypes.POINTER(_i64)]),
     "lvae_pair_bounds_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _int, _int, ctypes.c_void_p,
                                     ctypes.c_void_p, _i64, ctypes.c_void_p]),

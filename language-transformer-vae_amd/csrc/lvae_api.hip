@@ -6,13 +6,20 @@
 #include "pair_plan.h"
 
 // ---- launchers implemented in the kernel files --------------------------------------------------
-int lvae_launch_colsum(const float* mu, int64_t n, int D, PairHeader* hdr, hipStream_t st);
+int lvae_launch_colsum(const float* mu, int64_t n, int D, PairHeader* hdr, hipStream_t st, double* zero5 = nullptr);
 int lvae_launch_prep(int src, bool frag, const float* x, const float* spread, int spread_kind,
                      int64_t n, int64_t npad, int D, int DP, PairHeader* hdr, int64_t ngauss,
                      float* out, float* bias, float* dparams, int DC, hipStream_t st);
 int lvae_launch_prep_dparams(const float* mu, const float* spread, int spread_kind, int64_t n, int D,
                              int DC, float* dparams, const PairHeader* gate_hdr, float cond_limit,
                              hipStream_t st);
+int lvae_launch_prep_pair(const float* mu, const float* spread, int spread_kind, int64_t n, int64_t npad_r,
+                          const float* z, int64_t m, int64_t npad_c, int D, int DP, PairHeader* hdr, float* rfrag,
+                          float* rbias, float* dparams, int DC, float* cop, float cond_floor, hipStream_t st);
+int lvae_launch_finalize_small(const float2* partial_a, int nsplit_a, const float2* partial_b, int nsplit_b,
+                               int64_t cpad, int64_t C, float log_norm, float* out, float* out_max, float* out_sum,
+                               const PairHeader* hdr, float cond_limit, const float* z, const float* mu,
+                               const float* logvar, int D, double* sums, hipStream_t st);
 int lvae_launch_finalize(const float2* partial, int nsplit, int64_t cpad, int64_t C,
                          const float* colbias, float log_norm, float* out, float* out_max,
                          float* out_sum, const PairHeader* hdr, float cond_limit, int use_if_above,
@@ -243,11 +250,26 @@ extern "C" int lvae_log_qz_workspace_bytes(int64_t M, int64_t N, int D, int with
     return LVAE_OK;
 }
 
+// Optional tail of the driver below: the float64 sums of lvae_latent_sums_f32 for samples z_i drawn from
+// posterior (mu[i], logvar[i]) -- fused into the merge kernel on the small path.
+struct StatsTail {
+    const float* mu;
+    const float* logvar;
+    double* sums;
+};
+
+// Largest N * M served by the small path (five launches, running-maximum epilogue in one pass: its lower MFMA
+// rate costs less than the shift / redo / second-merge launches of the fixed-reference form up to ~5,800^2), and
+// the most samples its one-workgroup merge handles.
+#define LVAE_SMALL_PAIRS 33554432.0
+#define LVAE_SMALL_MAX_M 16384
+
 // Shared driver: samples on the kept axis, posteriors on the reduced axis.
 static int run_log_qz(const float* z, const float* mu, const float* spread, int spread_kind,
                       int64_t M, int64_t N, int D, float log_norm, int exclude_diag,
                       int64_t diag_offset, int path, float* log_qz, float* log_qz_pm, float* row_max,
-                      float* row_sum, void* ws, int64_t ws_bytes, hipStream_t st) {
+                      float* row_sum, void* ws, int64_t ws_bytes, hipStream_t st,
+                      const StatsTail* tail = nullptr) {
     int rc = check_pair_shapes(z, mu, spread, spread_kind, M, N, D);
     if (rc) return rc;
     LVAE_CHECK_ARG(path == LVAE_PATH_AUTO || path == LVAE_PATH_MFMA || path == LVAE_PATH_DIRECT ||
@@ -282,6 +304,46 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     if (p.DP == 0) joint_path = LVAE_PATH_DIRECT;
     const bool need_mfma = want_joint && joint_path != LVAE_PATH_DIRECT;
     const bool need_direct = with_pm || (want_joint && joint_path != LVAE_PATH_MFMA);
+
+    // ---- small problems: memset, column sums, ONE operand-prep launch, the pair kernel(s) with the running-maximum
+    //      epilogue, ONE merge (+ statistics) launch.  Same kernels, same device-side conditioning gate.
+    const double pairs = (double)N * (double)M;
+    const bool small = p.DP != 0 && !bx && want_joint && pairs <= LVAE_SMALL_PAIRS && M <= LVAE_SMALL_MAX_M &&
+                       !(with_pm && pairs >= LVAE_PM_BX_MIN_PAIRS) && !getenv("LVAE_NO_SMALL_PATH");
+    if (small) {
+        const bool gated_s = joint_path == LVAE_PATH_AUTO;
+        const float limit_s = gated_s ? LVAE_COND_LIMIT : -1.0f;
+        const bool djoint = joint_path != LVAE_PATH_MFMA;
+        LVAE_HIP(hipMemsetAsync(hdr, 0, sizeof(PairHeader), st));
+        rc = lvae_launch_colsum(mu, N, D, hdr, st, tail ? tail->sums : nullptr);
+        if (rc) return rc;
+        rc = lvae_launch_prep_pair(mu, spread, spread_kind, N, p.nblk * 32, z, M, p.cpad, D, p.DP, hdr, rfrag, rbias,
+                                   need_direct ? dparams : nullptr, p.DC, cop, gated_s ? LVAE_COND_LIMIT : INFINITY, st);
+        if (rc) return rc;
+        hipEvent_t prof_stop_s = prof_mark(st, nullptr);
+        if (need_mfma) {
+            rc = lvae_launch_pair_mfma(p, rfrag, rbias, cop, partial, hdr, limit_s, 0, exclude_diag != 0, diag_offset, 0,
+                                       nullptr, 0, nullptr, st);
+            if (rc) return rc;
+        }
+        if (need_direct) {
+            rc = lvae_launch_pair_direct(p, djoint, with_pm, z, dparams, dpartial, dpartial_pm,
+                                         (int*)(base + p.off_dflags), hdr, limit_s, 1, exclude_diag, diag_offset, st);
+            if (rc) return rc;
+        }
+        if (prof_stop_s) prof_mark(st, prof_stop_s);
+        rc = lvae_launch_finalize_small(need_mfma ? partial : nullptr, p.nsplit, djoint ? dpartial : nullptr, p.dsplit,
+                                        p.cpad, M, log_norm, log_qz, row_max, row_sum, hdr, limit_s, z,
+                                        tail ? tail->mu : nullptr, tail ? tail->logvar : nullptr, D,
+                                        tail ? tail->sums : nullptr, st);
+        if (rc) return rc;
+        if (with_pm) {
+            rc = lvae_launch_finalize_pm(dpartial_pm, p.dsplit, p.cpad, M, D, p.DC, log_norm,
+                                         (float*)(base + p.off_pmtmp), log_qz_pm, st);
+            if (rc) return rc;
+        }
+        return LVAE_OK;
+    }
 
     // Direct-form parameters (25 MB at C2) are only written when something will read them: always with
     // prod-marginals or a forced direct path; in AUTO mode by a separate kernel that runs iff the device-side
@@ -387,7 +449,18 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
                                      (float*)(base + p.off_pmtmp), log_qz_pm, st);
         if (rc) return rc;
     }
+    if (tail) return lvae_launch_latent_sums(z, tail->mu, tail->logvar, log_qz, log_qz_pm, M, D, tail->sums, st);
     return LVAE_OK;
+}
+
+extern "C" int lvae_latent_stats_f32(const float* z, const float* mu_all, const float* logvar_all, int64_t M, int64_t N,
+                                     int D, float log_norm, int path, const float* mu_local,
+                                     const float* logvar_local, float* log_qz, double* sums, void* ws,
+                                     int64_t ws_bytes, void* stream) {
+    LVAE_CHECK_ARG(log_qz && sums && mu_local && logvar_local, "log_qz, sums, mu_local and logvar_local must be non-NULL");
+    const StatsTail tail{mu_local, logvar_local, sums};
+    return run_log_qz(z, mu_all, logvar_all, LVAE_SPREAD_LOGVAR, M, N, D, log_norm, 0, 0, path, log_qz, nullptr, nullptr,
+                      nullptr, ws, ws_bytes, (hipStream_t)stream, &tail);
 }
 
 extern "C" int lvae_plan_info(int64_t M, int64_t N, int D, int prod_marginals, int64_t* out) {

@@ -91,17 +91,35 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
     if (tw_env) {
         ns = atoll(tw_env);
     } else {
+        // (1) The many-rounds rule, measured at C2 (N = M = 65,536): five rounds of smaller workgroups beat one round
+        //     of large ones by 2.4 % (sym: eight, the work per workgroup is uneven) -- as long as a split keeps
+        //     enough blocks to amortise the per-workgroup prologue (>= 128).
         double best = 1e300;
+        int64_t ns_rounds = 1;
         for (int64_t c = 1; c <= max_ns; ++c) {
-            // measured at C2: five rounds of smaller workgroups beat one round of large ones by 2.4 %
             if (groups * c < (sym ? 8 : 5) * slots && c < max_ns) continue;
             const int64_t rounds = lvae_ceil_div(groups * c, slots);
             const double cost = (double)rounds * ((double)lvae_ceil_div(p.nblk, c) + 4.0);
             if (cost < best * 0.999) {
                 best = cost;
-                ns = c;
+                ns_rounds = c;
             }
         }
+        // (2) Smaller problems (measured at 1,024^2 .. 16,384^2, tools/sweep_nsplit.py): a workgroup costs about four
+        //     blocks of prologue; a grid that fits one workgroup per CU runs each of them at ~1/0.55 the shared speed;
+        //     among near-ties the fewest splits win (the merge of the partials grows with them).
+        best = 1e300;
+        int64_t ns_model = 1;
+        for (int64_t c = 1; c <= max_ns; ++c) {
+            const int64_t wgs = groups * c;
+            const double bps = (double)lvae_ceil_div(p.nblk, c);
+            const double cost = wgs <= 256 ? 0.55 * bps + 4.0 : (double)lvae_ceil_div(wgs, slots) * (bps + 4.0);
+            if (cost < best * 0.97) {
+                best = cost;
+                ns_model = c;
+            }
+        }
+        ns = lvae_ceil_div(p.nblk, ns_rounds) >= 128 ? ns_rounds : ns_model;
     }
     if (ns > max_ns) ns = max_ns;
     if (ns < 1) ns = 1;

@@ -20,8 +20,10 @@
 // the slab is accumulated through LDS atomics.
 #define COLSUM_ROWS 512       // rows per workgroup: few enough workgroups that the float64 atomics on the D sums stay short
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ mu, int64_t n, int D,
-                                                     PairHeader* hdr) {
+                                                     PairHeader* hdr, double* __restrict__ zero5) {
     __shared__ float sm[256];
+    // (small path: the five float64 statistics a later kernel of this call adds into start from zero)
+    if (zero5 && blockIdx.x == 0 && threadIdx.x < 5) zero5[threadIdx.x] = 0.0;
     const int64_t r0 = (int64_t)blockIdx.x * COLSUM_ROWS;
     int64_t r1 = r0 + COLSUM_ROWS;
     if (r1 > n) r1 = n;
@@ -88,12 +90,14 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ m
 // rows -2y (k-half 0: dimension 2s, k-half 1: dimension 2s + 1) with bias |y|^2 (+inf on padded rows), SAMPLE
 // rows x with `bias` receiving |x|^2 (the per-column norm the epilogue adds); no centering shift.
 #define PREP_RB 4
+// (a device function so that one launch can prepare both operands of a small problem, prep_pair_kernel below:
+//  `wg` stands for blockIdx.x, `rb` for the 32-row blocks a workgroup covers)
 template <int SRC, bool FRAG>
-__global__ void __launch_bounds__(1024)
-prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ spread, int spread_kind,
-                    int64_t n, int64_t npad, int D, int DP, PairHeader* hdr, double inv_ngauss,
-                    float* __restrict__ out, float* __restrict__ bias, float* __restrict__ dparams,
-                    int DC) {
+__device__ __forceinline__ void
+prep_rows(const int64_t wg, const int rb, const float* __restrict__ x, const float* __restrict__ spread, int spread_kind,
+          int64_t n, int64_t npad, int D, int DP, PairHeader* hdr, double inv_ngauss,
+          float* __restrict__ out, float* __restrict__ bias, float* __restrict__ dparams,
+          int DC, float cond_floor = -1.f, bool want_norm = true) {
     constexpr bool GAUSS = SRC == 0;
     constexpr bool POINT = SRC == 2;
     constexpr bool LIN = SRC == 3 || SRC == 4;
@@ -107,8 +111,8 @@ prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ sprea
     const int q = tid % NQ;
     const bool vec = (D & 3) == 0 && 4 * q + 4 <= D;
     float cond_max = 0.f, norm_max = -INFINITY, norm_acc = 0.f;
-    for (int it = 0; it < PREP_RB; ++it) {
-        const int64_t blk = (int64_t)blockIdx.x * PREP_RB + it;
+    for (int it = 0; it < rb; ++it) {
+        const int64_t blk = wg * rb + it;
         if (blk * 32 >= npad) break;
         const int64_t row = blk * 32 + r;
         const bool valid = row < n;
@@ -235,12 +239,43 @@ prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ sprea
                 norm_acc += sm_w[w][2];
             }
             if (norm_max > -INFINITY) {      // at least one valid row
-                atomicMax(&hdr->cond_bits, __float_as_uint(cond_max));
-                atomicMax(&hdr->cmax_key, lvae_float_key(norm_max));
-                if (FRAG) atomicAdd(&hdr->norm_sum, (double)norm_acc);
+                // (the small path only needs to know WHETHER the conditioning estimate exceeds the gate's limit, and no
+                //  normaliser statistics: for well-conditioned inputs its workgroups issue no atomics at all -- 128
+                //  workgroups' atomics on these three words were a third of the launch at 4,096 posteriors)
+                if (cond_max > cond_floor) atomicMax(&hdr->cond_bits, __float_as_uint(cond_max));
+                if (want_norm) {
+                    atomicMax(&hdr->cmax_key, lvae_float_key(norm_max));
+                    if (FRAG) atomicAdd(&hdr->norm_sum, (double)norm_acc);
+                }
             }
         }
     }
+}
+
+template <int SRC, bool FRAG>
+__global__ void __launch_bounds__(1024)
+prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ spread, int spread_kind,
+                    int64_t n, int64_t npad, int D, int DP, PairHeader* hdr, double inv_ngauss,
+                    float* __restrict__ out, float* __restrict__ bias, float* __restrict__ dparams,
+                    int DC) {
+    prep_rows<SRC, FRAG>(blockIdx.x, PREP_RB, x, spread, spread_kind, n, npad, D, DP, hdr, inv_ngauss, out, bias,
+                         dparams, DC);
+}
+
+// Both operands of a small log q(z) problem in one launch (one 32-row block per workgroup: many small workgroups
+// instead of a few large ones): workgroups below wg_gauss prepare posterior rows (fragment-major, biases, header
+// statistics, direct-form parameters), the others sample rows.
+__global__ void __launch_bounds__(1024)
+prep_pair_kernel(const float* __restrict__ mu, const float* __restrict__ spread, int spread_kind, int64_t n,
+                 int64_t npad_r, const float* __restrict__ z, int64_t m, int64_t npad_c, int D, int DP,
+                 PairHeader* hdr, double inv_ngauss, float* __restrict__ rfrag, float* __restrict__ rbias,
+                 float* __restrict__ dparams, int DC, float* __restrict__ cop, int64_t wg_gauss, float cond_floor) {
+    if ((int64_t)blockIdx.x < wg_gauss)
+        prep_rows<0, true>(blockIdx.x, 1, mu, spread, spread_kind, n, npad_r, D, DP, hdr, inv_ngauss, rfrag, rbias,
+                           dparams, DC, cond_floor, false);
+    else
+        prep_rows<1, false>((int64_t)blockIdx.x - wg_gauss, 1, z, nullptr, 0, m, npad_c, D, DP, hdr, inv_ngauss, cop,
+                            nullptr, nullptr, DC);
 }
 
 // Direct-path parameters only (used when the MFMA path is not available for this D).
@@ -314,8 +349,10 @@ __global__ void finalize_lse_kernel(const float2* __restrict__ partial, int nspl
     for (int k = 0; k < nsplit; ++k) mx = fmaxf(mx, partial[k * cpad + i].x);
     double s = 0.0;
     for (int k = 0; k < nsplit; ++k) {
+        // (float32 exponent: the scale is exact -- 1 -- for the fixed-reference partials, which all carry 0, and
+        //  good to 1 ulp of a float32 sum otherwise; the float64 routine was the whole cost of this kernel)
         const float2 p = partial[k * cpad + i];
-        if (p.y > 0.f) s += (double)p.y * exp2((double)p.x - (double)mx);
+        if (p.y > 0.f) s += (double)p.y * (double)(p.x == mx ? 1.0f : lvae_exp2(p.x - mx));
     }
     if (flags_out && !(s >= (double)LSE_FLOOR)) flags_out[i / group_cols] = 1;
     const double cb = (colbias ? (double)colbias[i] : 0.0) + (use_ref ? (double)hdr->lse_ref : 0.0);
@@ -361,10 +398,10 @@ finalize_pm_sum_kernel(const float* __restrict__ tmp, int64_t cpad, int64_t C, i
 }
 
 // ---- host launchers ----------------------------------------------------------------------------
-int lvae_launch_colsum(const float* mu, int64_t n, int D, PairHeader* hdr, hipStream_t st) {
+int lvae_launch_colsum(const float* mu, int64_t n, int D, PairHeader* hdr, hipStream_t st, double* zero5) {
     if (D > 128) return lvae_set_error(LVAE_ERR_INVALID, "colsum: D > 128");
     const int64_t blocks = lvae_ceil_div(n, COLSUM_ROWS);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, mu, n, D, hdr);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, mu, n, D, hdr, zero5);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }
@@ -387,6 +424,17 @@ int lvae_launch_prep(int src, bool frag, const float* x, const float* spread, in
     else if (src == 2 && frag) LVAE_PREP(2, true);
     else return lvae_set_error(LVAE_ERR_INVALID, "prep: unsupported operand source");
 #undef LVAE_PREP
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+int lvae_launch_prep_pair(const float* mu, const float* spread, int spread_kind, int64_t n, int64_t npad_r,
+                          const float* z, int64_t m, int64_t npad_c, int D, int DP, PairHeader* hdr, float* rfrag,
+                          float* rbias, float* dparams, int DC, float* cop, float cond_floor, hipStream_t st) {
+    const int threads = 32 * (DP / 4);
+    const int64_t wg_r = npad_r / 32, wg_c = npad_c / 32;
+    hipLaunchKernelGGL(prep_pair_kernel, dim3((unsigned)(wg_r + wg_c)), dim3(threads), 0, st, mu, spread, spread_kind, n,
+                       npad_r, z, m, npad_c, D, DP, hdr, 1.0 / (double)n, rfrag, rbias, dparams, DC, cop, wg_r, cond_floor);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }

@@ -10,7 +10,7 @@
 //   iw_ll[b]   = LSE_k(log_p_x_z + log_p_z - log_q_z_x) - log K  loss_and_optimisation.py:783-794
 //
 // Algorithmic bytes per (sentence, sample): 4*D (eps) + 4 (log_p_x_z) read, + 4*D when z is written.
-#include "lvae_common.h"
+#include "pair_plan.h"
 
 __device__ __forceinline__ float group_sum(float v, int G) {
     for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -395,6 +395,127 @@ latent_sums_kernel(const float* __restrict__ z, const float* __restrict__ mu,
         atomicAdd(&sums[threadIdx.x], t);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) sums[4] = (double)M;
+}
+
+// Small problems: the merge of the split partials of whichever pair kernel ran -- MFMA (partial_a) or direct form
+// (partial_b); the device-side conditioning gate picks -- into log_qz, and optionally the float64 sums of
+// latent_sums_kernel in the same launch (one launch instead of six).  A row is served by G = D/4 consecutive lanes:
+// they share the row's split partials (online (max, sum) per lane, merged by shuffles) and its D-vector (one 16-byte
+// load each).  Partials are base-2 (max, sum) pairs without a fixed reference (running-maximum epilogue).  `sums`
+// must have been zeroed earlier on the stream (colsum_kernel does it): float64 atomics, as in latent_sums_kernel.
+__global__ void __launch_bounds__(256)
+finalize_small_kernel(const float2* __restrict__ partial_a, int nsplit_a, const float2* __restrict__ partial_b,
+                      int nsplit_b, int64_t cpad, int64_t C, float log_norm, float* __restrict__ out,
+                      float* __restrict__ out_max, float* __restrict__ out_sum,
+                      const PairHeader* __restrict__ hdr, float cond_limit, const float* __restrict__ z,
+                      const float* __restrict__ mu, const float* __restrict__ logvar, int D, int G, int passes,
+                      double* __restrict__ sums) {
+    const bool use_b = partial_a == nullptr || (cond_limit >= 0.f && __uint_as_float(hdr->cond_bits) > cond_limit);
+    const float2* __restrict__ partial = use_b ? partial_b : partial_a;
+    const int nsplit = use_b ? nsplit_b : nsplit_a;
+    const int gl = threadIdx.x % G;
+    const int rpp = 256 / G;                        // rows per pass
+    double a_lq = 0.0, a_lp = 0.0, a_lqx = 0.0;
+    // (a workgroup takes `passes` groups of rows: few workgroups keep the float64 atomics on the three sums short)
+    for (int ps = 0; ps < passes; ++ps) {
+        const int64_t row = ((int64_t)blockIdx.x * passes + ps) * rpp + threadIdx.x / G;
+        const bool ok = row < C;
+        float m = -INFINITY;
+        double sacc = 0.0;
+        if (ok) {
+#pragma unroll 4
+            for (int k = gl; k < nsplit; k += G) {
+                const float2 pp = partial[k * cpad + row];
+                if (pp.y > 0.f) {
+                    if (pp.x > m) {
+                        sacc = sacc * (double)lvae_exp2(m - pp.x) + (double)pp.y;      // exp2(-inf) = 0 the first time
+                        m = pp.x;
+                    } else {
+                        sacc += (double)pp.y * (double)lvae_exp2(pp.x - m);
+                    }
+                }
+            }
+        }
+        for (int o = G >> 1; o > 0; o >>= 1) {
+            const float mo = __shfl_xor(m, o, 64);
+            const double so = __shfl_xor(sacc, o, 64);
+            const float mm = fmaxf(m, mo);
+            sacc = (sacc > 0.0 ? sacc * (double)lvae_exp2(m - mm) : 0.0) + (so > 0.0 ? so * (double)lvae_exp2(mo - mm) : 0.0);
+            m = mm;
+        }
+        // sacc = f * 2^e with f in [0.5, 1): the float32 logarithm of f carries the full float32 result
+        int ex = 0;
+        const double fr = frexp(sacc, &ex);
+        const float lqz = sacc > 0.0 ? (float)(((double)m + (double)ex + (double)__log2f((float)fr)) * LVAE_LN2 - (double)log_norm)
+                                     : -INFINITY;
+        if (ok && gl == 0) {
+            if (out) out[row] = lqz;
+            if (out_max) {
+                out_max[row] = (float)((double)m * LVAE_LN2);
+                out_sum[row] = (float)sacc;
+            }
+        }
+        if (!sums) continue;
+        float lq = 0.f, lp = 0.f;
+        if (ok) {
+            if (G > 1 || D == 4) {
+                const f32x4 zz = *reinterpret_cast<const f32x4*>(z + row * D + 4 * gl);
+                const f32x4 mm = *reinterpret_cast<const f32x4*>(mu + row * D + 4 * gl);
+                const f32x4 lv = *reinterpret_cast<const f32x4*>(logvar + row * D + 4 * gl);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float df = zz[e] - mm[e];
+                    lq += -0.5f * (lv[e] + LVAE_LOG_2PI + __fdiv_rn(df * df, expf(lv[e])));
+                    lp += -0.5f * (LVAE_LOG_2PI + zz[e] * zz[e]);
+                }
+            } else {
+                for (int d = 0; d < D; ++d) {
+                    const float zz = z[row * D + d], mm = mu[row * D + d], lv = logvar[row * D + d];
+                    const float df = zz - mm;
+                    lq += -0.5f * (lv + LVAE_LOG_2PI + __fdiv_rn(df * df, expf(lv)));
+                    lp += -0.5f * (LVAE_LOG_2PI + zz * zz);
+                }
+            }
+        }
+        lq = group_sum(lq, G);
+        lp = group_sum(lp, G);
+        if (ok && gl == 0) {
+            a_lq += (double)lqz;
+            a_lp += (double)lp;
+            a_lqx += (double)lq;
+        }
+    }
+    if (!sums) return;
+    __shared__ double sm[3][4];
+    a_lq = wave_sum_d(a_lq);
+    a_lp = wave_sum_d(a_lp);
+    a_lqx = wave_sum_d(a_lqx);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sm[0][w] = a_lq;
+        sm[1][w] = a_lp;
+        sm[2][w] = a_lqx;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)      // {sum log_qz, (prod-marginals: 0), sum log p(z), sum log q(z|x), M}
+        atomicAdd(&sums[threadIdx.x == 0 ? 0 : threadIdx.x + 1],
+                  sm[threadIdx.x][0] + sm[threadIdx.x][1] + sm[threadIdx.x][2] + sm[threadIdx.x][3]);
+    if (blockIdx.x == 0 && threadIdx.x == 3) sums[4] = (double)C;
+}
+
+int lvae_launch_finalize_small(const float2* partial_a, int nsplit_a, const float2* partial_b, int nsplit_b,
+                               int64_t cpad, int64_t C, float log_norm, float* out, float* out_max, float* out_sum,
+                               const PairHeader* hdr, float cond_limit, const float* z, const float* mu,
+                               const float* logvar, int D, double* sums, hipStream_t st) {
+    int G = 1;
+    if (!vec_ok(D, &G)) G = 1;
+    const int64_t groups = lvae_ceil_div(C, 256 / G);
+    const int passes = 1;      // (more rows per workgroup were measured slower: the passes serialise on their loads)
+    hipLaunchKernelGGL(finalize_small_kernel, dim3((unsigned)lvae_ceil_div(groups, passes)), dim3(256), 0, st, partial_a,
+                       nsplit_a, partial_b, nsplit_b, cpad, C, log_norm, out, out_max, out_sum, hdr, cond_limit, z, mu,
+                       logvar, D, G, passes, sums);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
 }
 
 int lvae_launch_latent_sums(const float* z, const float* mu, const float* logvar, const float* log_qz,

@@ -85,12 +85,25 @@ def all_gather_rows(x, group=None, counts=None):
 
 def hip_local_stats(mu_all, logvar_all, z_local, mu_local, logvar_local, log_norm, prod_marginals, path=0):
     """Per-rank compute on the HIP path: float64 sums over this rank's rows of
-    [log q(z), log prod-marginals (or 0), log p(z), log q(z|x)] and the row count."""
+    [log q(z), log prod-marginals (or 0), log p(z), log q(z|x)] and the row count.  Without prod-marginals this is
+    one C call (lvae_latent_stats_f32: on small problems the sums ride on the kernel that merges the partials)."""
     from . import _native as N
     from . import estimators as E
-    log_q_z, log_q_z_pm = E.log_qz_raw(mu_all, logvar_all, z_local, log_norm, prod_marginals, path=path)
     z, mu, lv = (N.as_f32(t, n) for t, n in ((z_local, "z"), (mu_local, "mu"), (logvar_local, "logvar")))
     dev = z.device
+    if not prod_marginals:
+        mu_a, lv_a = N.as_f32(mu_all, "mu"), N.as_f32(logvar_all, "logvar")
+        M, D = z.shape
+        Nn = mu_a.shape[0]
+        with torch.cuda.device(dev):
+            ws, nbytes = E._pair_workspace(M, Nn, D, False, dev)
+            log_q_z = torch.empty(M, dtype=torch.float32, device=dev)
+            sums = torch.empty(5, dtype=torch.float64, device=dev)
+            N.check(N.lib().lvae_latent_stats_f32(N.ptr(z), N.ptr(mu_a), N.ptr(lv_a), M, Nn, D, float(log_norm), path,
+                                                  N.ptr(mu), N.ptr(lv), N.ptr(log_q_z), N.ptr(sums), N.ptr(ws), nbytes,
+                                                  N.stream_ptr(dev)))
+        return sums, log_q_z
+    log_q_z, log_q_z_pm = E.log_qz_raw(mu_all, logvar_all, z_local, log_norm, prod_marginals, path=path)
     with torch.cuda.device(dev):
         sums = torch.empty(5, dtype=torch.float64, device=dev)
         N.check(N.lib().lvae_latent_sums_f32(N.ptr(z), N.ptr(mu), N.ptr(lv), N.ptr(log_q_z),

@@ -20,7 +20,7 @@ def report(path):
     for e in re.split(r"\n\s+- \.agpr_count:", txt)[1:]:
         g = lambda k: re.search(r"\.%s:\s+(\S+)" % k, e).group(1)
         sym = g("name")
-        dem = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", sym], capture_output=True, text=True).stdout.strip()
+        dem = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.strip()
         dem = re.sub(r"\(.*", "", dem).replace("void ", "")
         rows.append((dem, int(re.match(r"\s*(\d+)", e).group(1)), int(g("vgpr_count")), int(g("vgpr_spill_count")),
                      int(g("private_segment_fixed_size")), int(g("group_segment_fixed_size"))))
