@@ -184,6 +184,29 @@ int lvae_reparam_iw_f32(const float* mu, const float* logvar, const float* eps, 
                         int64_t B, int64_t K, int D, float* z, float* log_q_z_x, float* log_p_z,
                         float* iw_ll, void* stream);
 
+/* The hot-path tail of EncoderNewsVAE.encode for ONE training batch (modules/encoder.py:79-107) as one launch:
+ * reparameterize (:148-157, noise injected), log q(z|x) and log p(z) per (b, k) (:93-98), approximate_log_q_z(method
+ * ="chen", prod_marginals=True) on the FIRST sample of every row with its two means (:102-104; log_norm = log(B *
+ * dataset_size), loss_and_optimisation.py:207) and maximum_mean_discrepancy of the first samples against
+ * prior_sample [B,D] (:107; NULL: no MMD).  The reference runs this every training step at B = 32, where it is
+ * launch-bound: the general entry points need ~40 launches for it.  Direct form throughout (no expansion).
+ * Outputs (each may be NULL): z [B,K,D], log_q_z_x / log_p_z [B,K], log_qz / log_qz_prod_marg [B] (per sample),
+ * scalars[3] = {mean log_qz, mean log_qz_prod_marg, mmd}.  Envelope (lvae_encode_tail_supported, host only, 1/0):
+ * B <= 128, B * D <= 4096, B * K * D <= 2^20; LVAE_ERR_UNSUPPORTED outside. */
+int lvae_encode_tail_supported(int64_t B, int64_t K, int D);
+int lvae_encode_tail_f32(const float* mu, const float* logvar, const float* eps, const float* prior_sample, int64_t B,
+                         int64_t K, int D, float log_norm, float* z, float* log_q_z_x, float* log_p_z, float* log_qz,
+                         float* log_qz_prod_marg, float* scalars, void* stream);
+
+/* Backward of lvae_encode_tail_f32 in one launch (what loss.backward() sends through encode(), loss_and_optimisation
+ * .py:925-1018): upstream gradients (each may be NULL) g_z [B,K,D], g_log_q_z_x / g_log_p_z [B,K], and one float each
+ * in device memory on the two MEANS (g_log_qz_mean, g_prod_marg_mean); the MMD carries no gradient (quirk Q5).
+ * Outputs: d_mu, d_logvar [B,D] (everything chained through z = mu + eps * exp(logvar / 2)).  Deterministic. */
+int lvae_encode_tail_bwd_f32(const float* mu, const float* logvar, const float* eps, int64_t B, int64_t K, int D,
+                             float log_norm, const float* g_z, const float* g_log_q_z_x, const float* g_log_p_z,
+                             const float* g_log_qz_mean, const float* g_prod_marg_mean, float* d_mu, float* d_logvar,
+                             void* stream);
+
 /* iw_log_p_x alone (loss_and_optimisation.py:783-794): three [B,K] inputs -> [B]. */
 int lvae_iw_lse_f32(const float* log_p_x_z, const float* log_p_z, const float* log_q_z_x, int64_t B,
                     int64_t K, float* out, void* stream);

@@ -136,6 +136,13 @@ int lvae_launch_gauss_ll_masked(const float* sample, const float* mu, const floa
                                 const int64_t* shape, const int64_t* st_s, const int64_t* st_mu,
                                 const int64_t* st_var, const int64_t* st_mask, int dim, int64_t n_out, float* out,
                                 hipStream_t st);
+bool lvae_encode_tail_tiny_ok(int64_t B, int64_t K, int D);
+int lvae_launch_encode_tail_tiny(const float* mu, const float* logvar, const float* eps, const float* prior, int64_t B,
+                                 int64_t K, int D, float log_norm, float* z, float* log_q_z_x, float* log_p_z,
+                                 float* log_qz, float* log_qz_pm, float* scalars, hipStream_t st);
+int lvae_launch_encode_tail_tiny_bwd(const float* mu, const float* logvar, const float* eps, int64_t B, int64_t K, int D,
+                                     float log_norm, const float* g_z, const float* g_lqx, const float* g_lpz,
+                                     const float* g_lq, const float* g_pm, float* d_mu, float* d_lv, hipStream_t st);
 int lvae_launch_mmd_stat(const double* sums, int64_t n1, int64_t n2, int unbiased, int zero_alphas,
                          double* out, hipStream_t st);
 
@@ -780,6 +787,36 @@ extern "C" int lvae_reparam_iw_f32(const float* mu, const float* logvar, const f
     LVAE_CHECK_ARG(z || log_q_z_x || log_p_z || iw_ll, "no output requested");
     return lvae_launch_sample_iw(true, mu, logvar, eps, log_p_x_z, B, K, D, z, log_q_z_x, log_p_z, iw_ll,
                                  (hipStream_t)stream);
+}
+
+// ---- the whole training-time tail of encode() for one small batch, one launch each way --------------------------
+extern "C" int lvae_encode_tail_supported(int64_t B, int64_t K, int D) { return lvae_encode_tail_tiny_ok(B, K, D) ? 1 : 0; }
+
+extern "C" int lvae_encode_tail_f32(const float* mu, const float* logvar, const float* eps, const float* prior_sample,
+                                    int64_t B, int64_t K, int D, float log_norm, float* z, float* log_q_z_x,
+                                    float* log_p_z, float* log_qz, float* log_qz_prod_marg, float* scalars,
+                                    void* stream) {
+    LVAE_CHECK_ARG(mu && logvar && eps, "mu, logvar and eps must be non-NULL");
+    LVAE_CHECK_ARG(z || log_q_z_x || log_p_z || log_qz || log_qz_prod_marg || scalars, "no output requested");
+    if (!lvae_encode_tail_tiny_ok(B, K, D))
+        return lvae_set_error(LVAE_ERR_UNSUPPORTED,
+                              "the one-launch encode tail serves B <= 128, B * D <= 4096, B * K * D <= 2^20 "
+                              "(got B=%lld K=%lld D=%d); use the general entry points", (long long)B, (long long)K, D);
+    return lvae_launch_encode_tail_tiny(mu, logvar, eps, prior_sample, B, K, D, log_norm, z, log_q_z_x, log_p_z, log_qz,
+                                        log_qz_prod_marg, scalars, (hipStream_t)stream);
+}
+
+extern "C" int lvae_encode_tail_bwd_f32(const float* mu, const float* logvar, const float* eps, int64_t B, int64_t K,
+                                        int D, float log_norm, const float* g_z, const float* g_log_q_z_x,
+                                        const float* g_log_p_z, const float* g_log_qz_mean,
+                                        const float* g_prod_marg_mean, float* d_mu, float* d_logvar, void* stream) {
+    LVAE_CHECK_ARG(mu && logvar && eps, "mu, logvar and eps must be non-NULL");
+    LVAE_CHECK_ARG(d_mu || d_logvar, "at least one output gradient is required");
+    if (!lvae_encode_tail_tiny_ok(B, K, D))
+        return lvae_set_error(LVAE_ERR_UNSUPPORTED, "outside the envelope of the one-launch encode tail (B=%lld K=%lld D=%d)",
+                              (long long)B, (long long)K, D);
+    return lvae_launch_encode_tail_tiny_bwd(mu, logvar, eps, B, K, D, log_norm, g_z, g_log_q_z_x, g_log_p_z,
+                                            g_log_qz_mean, g_prod_marg_mean, d_mu, d_logvar, (hipStream_t)stream);
 }
 
 extern "C" int lvae_iw_lse_f32(const float* log_p_x_z, const float* log_p_z, const float* log_q_z_x,

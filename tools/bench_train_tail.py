@@ -21,8 +21,10 @@ def eager_tail(mu, logvar, eps, dataset_size=10000):
     kl = (0.5 * (mu ** 2 + logvar.exp() - logvar - 1)).sum(1).mean()
     return lqx.mean() - lq + 3.0 * (lq - lqpm) + 0.5 * (lqpm - lpz.mean()) + 0.25 * kl
 
+FUSED = [None]
+
 def hip_tail(mu, logvar, eps):
-    out = EO.encode_tail(mu, logvar, n_samples=eps.shape[1], dataset_size=10000, eps=eps)
+    out = EO.encode_tail(mu, logvar, n_samples=eps.shape[1], dataset_size=10000, eps=eps, fused=FUSED[0])
     kl, _ = E.kl_divergence(mu, logvar, 0.5)
     return (out["log_q_z_x"].mean() - out["log_q_z"] + 3.0 * (out["log_q_z"] - out["log_q_z_prod_marg"])
             + 0.5 * (out["log_q_z_prod_marg"] - out["log_p_z"].mean()) + 0.25 * kl)
@@ -39,13 +41,24 @@ def timeit(fn, mu, logvar, eps, iters=50):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / iters * 1e6
 
-for B in (32, 128, 512, 2048):
+for B in (32, 64, 128, 512, 2048):
     g = torch.Generator(device="cuda").manual_seed(B)
     mu = torch.randn(B, 32, device="cuda", generator=g).requires_grad_(True)
     logvar = (0.5 * torch.randn(B, 32, device="cuda", generator=g) - 1).requires_grad_(True)
     eps = torch.randn(B, 1, 32, device="cuda", generator=g)
+    FUSED[0] = None          # default routing: the one-launch kernels whenever the batch fits
     a = timeit(hip_tail, mu, logvar, eps)
     ga = mu.grad.clone()
+    FUSED[0] = False         # the general kernel chain
+    c = timeit(hip_tail, mu, logvar, eps)
     b = timeit(eager_tail, mu, logvar, eps)
     err = float((ga - mu.grad).abs().max() / mu.grad.abs().max())
-    print(f"B={B}: HIP fwd+bwd {a:.0f} us   PyTorch eager (GPU) {b:.0f} us   grad rel diff {err:.1e}", flush=True)
+    with torch.no_grad():
+        FUSED[0] = None
+        f = lambda: EO.encode_tail(mu, logvar, n_samples=1, dataset_size=10000, eps=eps)
+        for _ in range(5): f()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(50): f()
+        torch.cuda.synchronize(); fw = (time.perf_counter() - t0) / 50 * 1e6
+    print(f"B={B}: HIP fwd+bwd {a:.0f} us (one-launch tail: {EO.tiny_tail_supported(B, 1, 32)}; general kernels {c:.0f} us; "
+          f"forward only, no grad {fw:.0f} us)   PyTorch eager (GPU) {b:.0f} us   grad rel diff {err:.1e}", flush=True)
