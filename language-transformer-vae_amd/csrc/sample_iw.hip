@@ -31,7 +31,36 @@ __device__ __forceinline__ void lse_push(float& m, float& s, float w) {
 // keeps U consecutive rows in flight (U independent 16-B loads per lane); after the shuffle reduction
 // lane u of the group owns row u's densities, so the [B,K] outputs and log_p_x_z move as runs of
 // consecutive floats (U per group, 64*U/G per wave-instruction) instead of one float per group.
-template <bool FROM_EPS, int U, int TPB>
+// Sum of U per-row partials over the G lanes of a row group, leaving row (gl % U) in lane gl: levels wider than U
+// are plain butterflies, the last log2(U) levels a reduce-scatter (each level halves what a lane still carries):
+// G = U = 8 takes 7 shuffles per quantity instead of 24.
+template <int U>
+__device__ __forceinline__ float reduce_rows(float (&a)[U], int gl, int G) {
+    for (int o = G >> 1; o >= U; o >>= 1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] += __shfl_xor(a[u], o, 64);
+    }
+#pragma unroll
+    for (int o = U >> 1; o >= 1; o >>= 1) {
+        const bool up = (gl & o) != 0;
+#pragma unroll
+        for (int u = 0; u < o; ++u) {
+            const float send = up ? a[u] : a[u + o];
+            const float keep = up ? a[u + o] : a[u];
+            a[u] = keep + __shfl_xor(send, o, 64);
+        }
+    }
+    return a[0];
+}
+
+// z = mu + eps * sigma with the product and the sum rounded separately, like the reference's torch.mul / + (no fma)
+__device__ __forceinline__ f32x2 mul_then_add(f32x2 m, f32x2 e, f32x2 sd) {
+#pragma clang fp contract(off)
+    const f32x2 t = e * sd;
+    return m + t;
+}
+
+template <bool FROM_EPS, int U, int TPB, bool PIPE>
 __global__ void __launch_bounds__(TPB)
 sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
                  const float* __restrict__ src, const float* __restrict__ log_p_x_z, int64_t K, int D,
@@ -41,17 +70,6 @@ sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
     const int gl = threadIdx.x % G;          // lane inside the row group: owns dims 4*gl .. 4*gl+3
     const int rows_per_iter = (TPB / G) * U;
     const bool have_post = mu != nullptr;
-    f32x4 m4 = {0.f, 0.f, 0.f, 0.f}, lv4 = m4, sd4 = m4, iv4 = m4;
-    if (have_post) {
-        m4 = *reinterpret_cast<const f32x4*>(mu + b * D + 4 * gl);
-        lv4 = *reinterpret_cast<const f32x4*>(logvar + b * D + 4 * gl);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            sd4[e] = expf(0.5f * lv4[e]);
-            iv4[e] = 1.0f / expf(lv4[e]);      // 1/var: the streaming loop multiplies instead of dividing
-        }
-    }
-    float lm = -INFINITY, ls = 0.f;
     const float* __restrict__ base = src + b * K * D;
     // Row of (group g of the wave, load u) = wave base + u * Gw + g: one wave-instruction reads Gw
     // consecutive rows = 1 KiB of contiguous memory, and the 64 results a wave owns are 64 consecutive
@@ -59,47 +77,88 @@ sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
     const int Gw = 64 / G;                                // row groups per wave
     const int gw = (threadIdx.x & 63) / G;                // this lane's group inside its wave
     const int wave_rows = Gw * U;
-    for (int64_t k0 = 0; k0 < K; k0 += rows_per_iter) {
-        const int64_t kw = k0 + (int64_t)(threadIdx.x >> 6) * wave_rows + gw;   // row of load 0
-        f32x4 v[U];
+    const int64_t kw0 = (int64_t)(threadIdx.x >> 6) * wave_rows + gw;           // row of load 0 in pass 0
+    // (unconditional loads: a row past the end is clamped to the last one -- its results are never owned by a lane
+    //  -- so that a pass is straight-line code and the waits on its loads are counted ones)
+    const int64_t klast = K - 1;
+    auto issue = [&](f32x4 (&v)[U], int64_t kw) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (kw + u * Gw < K)
-                v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (kw + u * Gw) * D + 4 * gl));
+            const int64_t row = kw + u * Gw < klast ? kw + u * Gw : klast;
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + row * D + 4 * gl));
         }
-        const int64_t kmine = kw + (int64_t)gl * Gw;     // the row whose results this lane will own
+    };
+    // The stream is software-pipelined over two register buffers: the loads of pass p + 1 are in flight while pass
+    // p is reduced (7 dependent shuffles per quantity), and the first pass is issued before the per-lane constants
+    // -- which hang on a load of their own -- are formed.
+    f32x4 va[U], vb[U];
+    issue(va, kw0);
+    // per-lane constants of the four dimensions, as two packed pairs: mean, sigma, sqrt(0.5 / var); the constant
+    // part of the row's log q(z|x), -0.5 (logvar + log 2pi), is summed once
+    f32x2 m2[2] = {{0.f, 0.f}, {0.f, 0.f}}, sd2[2] = {{0.f, 0.f}, {0.f, 0.f}}, sh2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float cq = 0.f;
+    if (have_post) {
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(mu + b * D + 4 * gl);
+        const f32x4 lv4 = *reinterpret_cast<const f32x4*>(logvar + b * D + 4 * gl);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            m2[e >> 1][e & 1] = m4[e];
+            sd2[e >> 1][e & 1] = expf(0.5f * lv4[e]);
+            sh2[e >> 1][e & 1] = sqrtf(0.5f / expf(lv4[e]));
+            cq += -0.5f * (lv4[e] + LVAE_LOG_2PI);
+        }
+    }
+    const float cp = -0.5f * LVAE_LOG_2PI * 4.0f;
+    float lm = -INFINITY, ls = 0.f;
+    auto consume = [&](const f32x4 (&v)[U], int64_t kw) {
+        const int64_t kmine = kw + (int64_t)(gl % U) * Gw;     // the row whose results this lane will own
         const bool mine = gl < U && kmine < K;
         float pxz = 0.f;
         if (mine && iw_ll && log_p_x_z) pxz = log_p_x_z[b * K + kmine];
-        float my_lq = 0.f, my_lp = 0.f;
+        // packed fp32 throughout (two dimensions per instruction): -(z - mu)^2 / (2 var) as the square of
+        // (z - mu) * sqrt(0.5 / var), -z^2 / 2 from the plain sum of squares
+        float aq[U], ap[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            f32x4 zz;
-            float lq = 0.f, lp = 0.f;
+            f32x2 q2 = {0.f, 0.f}, p2 = {0.f, 0.f};
+            f32x4 zz4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                // separate multiply and add, like the reference (no fused contraction)
-                zz[e] = FROM_EPS ? __fadd_rn(m4[e], __fmul_rn(v[u][e], sd4[e])) : v[u][e];
+            for (int h = 0; h < 2; ++h) {
+                const f32x2 x2 = {v[u][2 * h], v[u][2 * h + 1]};
+                const f32x2 zz = FROM_EPS ? mul_then_add(m2[h], x2, sd2[h]) : x2;
                 if (have_post) {
-                    const float df = zz[e] - m4[e];
-                    lq += -0.5f * (lv4[e] + LVAE_LOG_2PI + df * df * iv4[e]);
+                    const f32x2 w = (zz - m2[h]) * sh2[h];
+                    q2 = __builtin_elementwise_fma(w, w, q2);
                 }
-                lp += -0.5f * (LVAE_LOG_2PI + zz[e] * zz[e]);
+                p2 = __builtin_elementwise_fma(zz, zz, p2);
+                zz4[2 * h] = zz[0];
+                zz4[2 * h + 1] = zz[1];
             }
             if (FROM_EPS && z_out && kw + u * Gw < K)
-                __builtin_nontemporal_store(zz, reinterpret_cast<f32x4*>(z_out + (b * K + kw + u * Gw) * D + 4 * gl));
-            lq = group_sum(lq, G);
-            lp = group_sum(lp, G);
-            if (gl == u) {
-                my_lq = lq;
-                my_lp = lp;
-            }
+                __builtin_nontemporal_store(zz4, reinterpret_cast<f32x4*>(z_out + (b * K + kw + u * Gw) * D + 4 * gl));
+            aq[u] = cq - (q2[0] + q2[1]);
+            ap[u] = cp - 0.5f * (p2[0] + p2[1]);
         }
+        const float my_lq = have_post ? reduce_rows<U>(aq, gl, G) : 0.f;
+        const float my_lp = reduce_rows<U>(ap, gl, G);
         if (mine) {
             if (log_q_z_x) log_q_z_x[b * K + kmine] = my_lq;
             if (log_p_z) log_p_z[b * K + kmine] = my_lp;
             if (iw_ll) lse_push(lm, ls, pxz + my_lp - my_lq);
+        }
+    };
+    if (PIPE) {
+        for (int64_t k0 = 0; k0 < K; k0 += 2 * rows_per_iter) {
+            const bool second = k0 + rows_per_iter < K;
+            if (second) issue(vb, kw0 + k0 + rows_per_iter);
+            consume(va, kw0 + k0);
+            if (k0 + 2 * rows_per_iter < K) issue(va, kw0 + k0 + 2 * rows_per_iter);
+            if (second) consume(vb, kw0 + k0 + rows_per_iter);
+        }
+    } else {
+        for (int64_t k0 = 0; k0 < K; k0 += rows_per_iter) {
+            if (k0) issue(va, kw0 + k0);
+            consume(va, kw0 + k0);
         }
     }
     if (iw_ll) {
@@ -271,21 +330,28 @@ int lvae_launch_sample_iw(bool from_eps, const float* mu, const float* logvar, c
         // rows per pass of a workgroup = (threads / G) * U: narrower workgroups when a sentence has few samples
         // (K = 100 at 256 threads leaves 61 % of the lanes idle: 0.35 -> 0.21 ms at B = 65,536); wider ones than
         // 256 only lose (measured at C5: 0.46 / 0.52 / 0.63 ms at 256 / 512 / 1024 threads)
-        const int umax = G < 8 ? G : 8;
+        // U = loads in flight per lane in one pass, software-pipelined over two register buffers.  Measured at C5
+        // (tools/bench_iw_variants.py; LVAE_IW_PIPE / LVAE_IW_U override for such sweeps): when z is written, U = 8
+        // (0.77 ms, 5.7 TB/s; U = 4: 0.80); the read-only reduction prefers U = 4 -- fewer registers, more waves,
+        // 16 KB passes -- at 0.41 ms = 5.6 TB/s (U = 8: 0.47; the un-pipelined U = 8 kernel of round 1: 0.44).
+        int umax = G < 8 ? G : 8;
+        if (!(from_eps && z_out) && umax > 4) umax = 4;
+        bool pipe = true;
+        if (getenv("LVAE_IW_PIPE")) pipe = atoi(getenv("LVAE_IW_PIPE")) != 0;
+        if (getenv("LVAE_IW_U") && atoi(getenv("LVAE_IW_U")) < umax) umax = atoi(getenv("LVAE_IW_U"));
         const int tpb = K <= (64 / G) * umax ? 64 : (K <= (128 / G) * umax ? 128 : 256);
+        if (K <= (int64_t)(tpb / G) * umax * 2 && !getenv("LVAE_IW_PIPE")) pipe = false;     // one or two passes: the
+                                                          // single-buffer form needs fewer registers (more waves)
+#define LVAE_SIW2(E, UU, T, P)                                                                             \
+    hipLaunchKernelGGL((sample_iw_kernel<E, UU, T, P>), grid, dim3(T), 0, st, mu, logvar, src, log_p_x_z, K, D, G, \
+                       z_out, log_q_z_x, log_p_z, iw_ll)
 #define LVAE_SIW(E, UU)                                                                             \
     do {                                                                                            \
-        if (tpb == 64)                                                                              \
-            hipLaunchKernelGGL((sample_iw_kernel<E, UU, 64>), grid, dim3(64), 0, st, mu, logvar, src, log_p_x_z, K, \
-                               D, G, z_out, log_q_z_x, log_p_z, iw_ll);                             \
-        else if (tpb == 128)                                                                        \
-            hipLaunchKernelGGL((sample_iw_kernel<E, UU, 128>), grid, dim3(128), 0, st, mu, logvar, src, log_p_x_z, K, \
-                               D, G, z_out, log_q_z_x, log_p_z, iw_ll);                             \
-        else                                                                                        \
-            hipLaunchKernelGGL((sample_iw_kernel<E, UU, 256>), grid, dim3(256), 0, st, mu, logvar, src, log_p_x_z, K, \
-                               D, G, z_out, log_q_z_x, log_p_z, iw_ll);                             \
+        if (tpb == 64) { if (pipe) LVAE_SIW2(E, UU, 64, true); else LVAE_SIW2(E, UU, 64, false); }        \
+        else if (tpb == 128) { if (pipe) LVAE_SIW2(E, UU, 128, true); else LVAE_SIW2(E, UU, 128, false); } \
+        else { if (pipe) LVAE_SIW2(E, UU, 256, true); else LVAE_SIW2(E, UU, 256, false); }                \
     } while (0)
-        const int U = G < 8 ? G : 8;
+        const int U = umax;
         if (from_eps) {
             if (U == 8) LVAE_SIW(true, 8); else if (U == 4) LVAE_SIW(true, 4);
             else if (U == 2) LVAE_SIW(true, 2); else LVAE_SIW(true, 1);
@@ -293,6 +359,7 @@ int lvae_launch_sample_iw(bool from_eps, const float* mu, const float* logvar, c
             if (U == 8) LVAE_SIW(false, 8); else if (U == 4) LVAE_SIW(false, 4);
             else if (U == 2) LVAE_SIW(false, 2); else LVAE_SIW(false, 1);
         }
+#undef LVAE_SIW2
 #undef LVAE_SIW
     } else {
         if (from_eps)

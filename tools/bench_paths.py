@@ -22,7 +22,7 @@ def main():
     mu = torch.randn(B, D, device="cuda", generator=g); lv = 0.5 * torch.randn(B, D, device="cuda", generator=g) - 1
     eps = torch.randn(B, K, D, device="cuda", generator=g); lpxz = 5 * torch.randn(B, K, device="cuda", generator=g) - 100
     t = timed(lambda: E.reparam_iw(mu, lv, eps, lpxz, return_z=False))
-    by = B * K * (4 * D + 4)
+    by = B * K * (4 * D + 4 + 8)      # eps + log_p_x_z read, log_q_z_x + log_p_z written
     print(f"IW C5 no-z : {t*1e3:.3f} ms  {B*K/t:.3e} (sentence,sample)/s  {by/t/1e9:.0f} GB/s algorithmic ({by/t/8e12*100:.1f}% of 8 TB/s)", flush=True)
     t = timed(lambda: E.reparam_iw(mu, lv, eps, lpxz, return_z=True))
     by = B * K * (8 * D + 4 + 8)
