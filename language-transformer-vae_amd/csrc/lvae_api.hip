@@ -143,6 +143,15 @@ int lvae_launch_encode_tail_tiny(const float* mu, const float* logvar, const flo
 int lvae_launch_encode_tail_tiny_bwd(const float* mu, const float* logvar, const float* eps, int64_t B, int64_t K, int D,
                                      float log_norm, const float* g_z, const float* g_lqx, const float* g_lpz,
                                      const float* g_lq, const float* g_pm, float* d_mu, float* d_lv, hipStream_t st);
+bool lvae_pair_multi_supported(int DP, int epi);
+int lvae_launch_pair_multi(int DP, const PairJobs& jobs, int njobs, const PairHeader* hdr, bool excl, int epi,
+                           hipStream_t st);
+int lvae_launch_prep_ksum_multi(const float* const* x, const int64_t* n, const int64_t* npad, float* const* out,
+                                float* const* bias, const int* point, int njobs, int D, int DP, PairHeader* hdr,
+                                hipStream_t st);
+int lvae_launch_finalize_ksum_multi(const double* const* partial, const int* nsplit, const int64_t* cpad, const int64_t* C,
+                                    int nsets, double* out, hipStream_t st);
+int lvae_launch_ksum_init(PairHeader* hdr, const KsumParams& kp, double* zero, int nzero, hipStream_t st);
 int lvae_launch_mmd_stat(const double* sums, int64_t n1, int64_t n2, int unbiased, int zero_alphas,
                          double* out, hipStream_t st);
 
@@ -1050,10 +1059,49 @@ static size_t mmd_pair_extent(int64_t n1, int64_t n2, int D) {
     return e;
 }
 
+// Fused form of lvae_mmd_rbf_f32 (D <= 128, fp32 contraction, single-exponential epilogues): the POINT and SAMPLE
+// operands of both samples live side by side and the three kernel matrices are ONE launch (pair_lse_multi_kernel):
+//   header | x POINT frag + bias | y POINT frag + bias | x SAMPLE rows + norms | y SAMPLE rows + norms |
+//   partials (x,y) | partials (x,x) | partials (y,y) | 4 float64
+struct MmdFusedLayout {
+    PairPlan pxy, pxx, pyy;
+    size_t off_xr, off_xrb, off_yr, off_yrb, off_xc, off_xn, off_yc, off_yn, off_pxy, off_pxx, off_pyy, off_sums, total;
+};
+static MmdFusedLayout mmd_fused_layout(int64_t n1, int64_t n2, int D) {
+    MmdFusedLayout L;
+    const int dp = ksum_plan_dim(D);
+    L.pxy = lvae_make_pair_plan(n2, n1, dp, false, 0, false);
+    L.pxx = lvae_make_pair_plan(n1, n1, dp, false, 0, true);
+    L.pyy = lvae_make_pair_plan(n2, n2, dp, false, 0, true);
+    const int DP = L.pxy.DP;
+    size_t o = lvae_align256(sizeof(PairHeader));
+    auto take = [&](size_t bytes) { const size_t at = o; o = lvae_align256(o + bytes); return at; };
+    L.off_xr = take((size_t)L.pxx.nblk * DP * 64 * sizeof(float));
+    L.off_xrb = take(((size_t)L.pxx.nblk * 32 + 64) * sizeof(float));
+    L.off_yr = take((size_t)L.pyy.nblk * DP * 64 * sizeof(float));
+    L.off_yrb = take(((size_t)L.pyy.nblk * 32 + 64) * sizeof(float));
+    L.off_xc = take((size_t)L.pxx.cpad * 2 * DP * sizeof(float));
+    L.off_xn = take((size_t)L.pxx.cpad * sizeof(float));
+    L.off_yc = take((size_t)L.pyy.cpad * 2 * DP * sizeof(float));
+    L.off_yn = take((size_t)L.pyy.cpad * sizeof(float));
+    L.off_pxy = take((size_t)L.pxy.nsplit * L.pxy.cpad * sizeof(double));
+    L.off_pxx = take((size_t)L.pxx.nsplit * L.pxx.cpad * sizeof(double));
+    L.off_pyy = take((size_t)L.pyy.nsplit * L.pyy.cpad * sizeof(double));
+    L.off_sums = take(4 * sizeof(double));
+    L.total = o;
+    return L;
+}
+static bool mmd_fused_dims(int D) { return ksum_plan_dim(D) <= 64; }
+
 extern "C" int lvae_mmd_workspace_bytes(int64_t n1, int64_t n2, int D, int64_t* out_bytes) {
     LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
     LVAE_CHECK_ARG(n1 >= 2 && n2 >= 2 && D >= 1, "need n1, n2 >= 2 and D >= 1");
-    *out_bytes = (int64_t)(mmd_pair_extent(n1, n2, D) + 256);
+    size_t need = mmd_pair_extent(n1, n2, D) + 256;           // one pass at a time (wide latents, split-bf16 mode, ...)
+    if (mmd_fused_dims(D)) {
+        const size_t f = mmd_fused_layout(n1, n2, D).total;   // all three passes side by side
+        if (f > need) need = f;
+    }
+    *out_bytes = (int64_t)need;
     return LVAE_OK;
 }
 
@@ -1141,6 +1189,59 @@ extern "C" int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int6
     int rc = build_ksum(alphas, n_alpha, dist_eps, &kp, &zeros);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    const bool all_zero = kp.n == 0 && kp.c[0] == 0.f;
+    if (!all_zero && mmd_fused_dims(D) && g_pair_math.load() == LVAE_MATH_FP32 &&
+        lvae_pair_multi_supported(lvae_pad_dim(ksum_plan_dim(D)), ksum_epi(kp)) && !getenv("LVAE_NO_FUSED_MMD")) {
+        // ---- fused form: five launches (init, one operand prep, one pair launch for the three matrices, one total,
+        //      the statistic) instead of eighteen
+        const MmdFusedLayout L = mmd_fused_layout(n1, n2, D);
+        rc = check_ws(ws, ws_bytes, L.total);
+        if (rc) return rc;
+        char* base = (char*)ws;
+        PairHeader* hdr = (PairHeader*)base;
+        double* sums = (double*)(base + L.off_sums);
+        const int DP = L.pxy.DP;
+        rc = lvae_launch_ksum_init(hdr, kp, sums, 4, st);
+        if (rc) return rc;
+        float* xr = (float*)(base + L.off_xr);  float* xrb = (float*)(base + L.off_xrb);
+        float* yr = (float*)(base + L.off_yr);  float* yrb = (float*)(base + L.off_yrb);
+        float* xc = (float*)(base + L.off_xc);  float* xn = (float*)(base + L.off_xn);
+        float* yc = (float*)(base + L.off_yc);  float* yn = (float*)(base + L.off_yn);
+        {
+            const float* src[4] = {x, y, x, y};
+            const int64_t nn[4] = {n1, n2, n1, n2};
+            const int64_t npad[4] = {L.pxx.nblk * 32, L.pyy.nblk * 32, L.pxx.cpad, L.pyy.cpad};
+            float* outp[4] = {xr, yr, xc, yc};
+            float* bias[4] = {xrb, yrb, xn, yn};
+            const int point[4] = {1, 1, 0, 0};
+            rc = lvae_launch_prep_ksum_multi(src, nn, npad, outp, bias, point, 4, D, DP, hdr, st);
+            if (rc) return rc;
+        }
+        const bool excl = unbiased != 0;
+        const int64_t no_diag = (int64_t)1 << 40;             // the cross term has no diagonal to leave out
+        PairJobs jobs{};
+        auto fill = [&](PairJob& J, const PairPlan& p, const float* rf, const float* rb, const float* cp, const float* cn,
+                        size_t off_partial, int sym, int64_t excl_offset) {
+            J.rfrag = rf; J.rbias = rb; J.cop = cp; J.colnorm = cn; J.partial = (float2*)(base + off_partial);
+            J.nblk = p.nblk; J.blk_per_split = p.blk_per_split; J.cpad = p.cpad; J.excl_offset = excl_offset;
+            J.sym = sym; J.gx = (int)(p.cpad / (128 * p.NCB)); J.gy = p.nsplit;
+        };
+        fill(jobs.j[0], L.pxy, yr, yrb, xc, xn, L.off_pxy, 0, no_diag);     // kept = x, reduced = y: the fullest first
+        fill(jobs.j[1], L.pxx, xr, xrb, xc, xn, L.off_pxx, 1, 0);
+        fill(jobs.j[2], L.pyy, yr, yrb, yc, yn, L.off_pyy, 1, 0);
+        rc = lvae_launch_pair_multi(DP, jobs, 3, hdr, excl, ksum_epi(kp), st);
+        if (rc) return rc;
+        {
+            const double* parts[3] = {(const double*)(base + L.off_pxx), (const double*)(base + L.off_pyy),
+                                      (const double*)(base + L.off_pxy)};          // sums = {xx, yy, xy}
+            const int ns[3] = {L.pxx.nsplit, L.pyy.nsplit, L.pxy.nsplit};
+            const int64_t cpads[3] = {L.pxx.cpad, L.pyy.cpad, L.pxy.cpad};
+            const int64_t cs[3] = {n1, n2, n1};
+            rc = lvae_launch_finalize_ksum_multi(parts, ns, cpads, cs, 3, sums, st);
+            if (rc) return rc;
+        }
+        return lvae_launch_mmd_stat(sums, n1, n2, unbiased, zeros, out, st);
+    }
     const size_t extent = mmd_pair_extent(n1, n2, D);
     rc = check_ws(ws, ws_bytes, extent + 256);
     if (rc) return rc;

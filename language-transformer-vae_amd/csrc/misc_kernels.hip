@@ -343,6 +343,22 @@ __global__ void mmd_stat_kernel(const double* __restrict__ sums, double n1, doub
     out[3] = sxy;
 }
 
+// The same with the header cleared first and `nzero` float64 accumulators zeroed: the first launch of the fused MMD
+// call (no separate fills).
+__global__ void __launch_bounds__(256) ksum_init_kernel(PairHeader* hdr, const KsumParams kp, double* zero, int nzero) {
+    unsigned* w = reinterpret_cast<unsigned*>(hdr);
+    for (int i = threadIdx.x; i < (int)(sizeof(PairHeader) / sizeof(unsigned)); i += 256) w[i] = 0u;
+    if ((int)threadIdx.x < nzero) zero[threadIdx.x] = 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) hdr->ksum = kp;
+}
+
+int lvae_launch_ksum_init(PairHeader* hdr, const KsumParams& kp, double* zero, int nzero, hipStream_t st) {
+    hipLaunchKernelGGL(ksum_init_kernel, dim3(1), dim3(256), 0, st, hdr, kp, zero, nzero);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
 int lvae_launch_set_ksum(PairHeader* hdr, const KsumParams& kp, hipStream_t st) {
     hipLaunchKernelGGL(set_ksum_kernel, dim3(1), dim3(64), 0, st, hdr, kp);
     LVAE_LAUNCH_CHECK();

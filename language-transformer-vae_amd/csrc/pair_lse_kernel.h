@@ -76,14 +76,16 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 
 typedef __bf16 lvae_bf16x8 __attribute__((ext_vector_type(8)));
 
+// (the body is a device function: pair_lse_mfma_kernel below runs one job per launch, pair_lse_multi_kernel up to
+//  three kernel-sum jobs selected by blockIdx.z)
 template <int DP, int NCB, int WPS, bool EXCL, int EPI, bool PERM = false, bool BX = false>
-__global__ void __launch_bounds__(256, WPS)
-pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ rbias,
-                     const float* __restrict__ cop, float2* __restrict__ partial,
-                     const PairHeader* __restrict__ hdr, float cond_limit, int use_if_above,
-                     int64_t nblk, int64_t blk_per_split, int64_t cpad, int64_t excl_offset,
-                     PermArgs pa, const int* __restrict__ redo_flags, int sym,
-                     const float* __restrict__ colnorm) {
+__device__ __forceinline__ void
+pair_lse_body(const float* __restrict__ rfrag, const float* __restrict__ rbias,
+              const float* __restrict__ cop, float2* __restrict__ partial,
+              const PairHeader* __restrict__ hdr, float cond_limit, int use_if_above,
+              int64_t nblk, int64_t blk_per_split, int64_t cpad, int64_t excl_offset,
+              const PermArgs& pa, const int* __restrict__ redo_flags, int sym,
+              const float* __restrict__ colnorm) {
     static_assert(!PERM || (NCB == 1 && (EPI == 1 || EPI == 2 || EPI == 5)), "PERM needs NCB == 1 and a polynomial epilogue");
     constexpr bool KS = EPI == 1 || EPI == 2 || EPI == 3 || EPI == 5;      // kernel-sum epilogues
     static_assert(!BX || DP <= 64, "the split-bf16 contraction is built for D <= 64");
@@ -681,5 +683,32 @@ pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ 
         const float ss = s[cb] * lvae_exp2(m[cb] - mm) + so * lvae_exp2(mo - mm);
         if (h == 0) partial[(int64_t)blockIdx.y * cpad + col0 + cb * 32 + r] = make_float2(mm, ss);
     }
+}
+
+template <int DP, int NCB, int WPS, bool EXCL, int EPI, bool PERM = false, bool BX = false>
+__global__ void __launch_bounds__(256, WPS)
+pair_lse_mfma_kernel(const float* __restrict__ rfrag, const float* __restrict__ rbias,
+                     const float* __restrict__ cop, float2* __restrict__ partial,
+                     const PairHeader* __restrict__ hdr, float cond_limit, int use_if_above,
+                     int64_t nblk, int64_t blk_per_split, int64_t cpad, int64_t excl_offset,
+                     PermArgs pa, const int* __restrict__ redo_flags, int sym,
+                     const float* __restrict__ colnorm) {
+    pair_lse_body<DP, NCB, WPS, EXCL, EPI, PERM, BX>(rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, nblk,
+                                                     blk_per_split, cpad, excl_offset, pa, redo_flags, sym, colnorm);
+}
+
+// Up to three kernel-sum jobs in ONE launch (the three kernel matrices of an MMD: cross term first, it is the
+// fullest): blockIdx.z picks the job, workgroups beyond a job's own grid exit.  One ramp-up and one tail instead
+// of three, and the uneven workgroups of the symmetric jobs fill in behind each other.
+
+template <int DP, int NCB, int WPS, bool EXCL, int EPI>
+__global__ void __launch_bounds__(256, WPS)
+pair_lse_multi_kernel(const PairJobs jobs, const PairHeader* __restrict__ hdr) {
+    const PairJob& J = jobs.j[blockIdx.z];
+    if ((int)blockIdx.x >= J.gx || (int)blockIdx.y >= J.gy) return;
+    const PermArgs pa{};
+    pair_lse_body<DP, NCB, WPS, EXCL, EPI, false, false>(J.rfrag, J.rbias, J.cop, J.partial, hdr, -1.f, 0, J.nblk,
+                                                         J.blk_per_split, J.cpad, J.excl_offset, pa, nullptr, J.sym,
+                                                         J.colnorm);
 }
 #endif  // LVAE_PAIR_LSE_KERNEL_H

@@ -110,3 +110,45 @@ int lvae_launch_pair_mfma_perm(const PairPlan& p, const float* rfrag, const floa
             return lvae_set_error(LVAE_ERR_UNSUPPORTED, "MFMA path needs D <= 128 (got D=%d)", p.D);
     }
 }
+
+// Three kernel-sum jobs in one launch (pair_lse_multi_kernel).  Served: D <= 128 (plan dimension 16 / 32 / 64) and the
+// single-exponential epilogues (1, 2, 5); anything else returns LVAE_ERR_UNSUPPORTED and the caller runs the jobs
+// one by one.
+template <int DP, int NCB, int WPS>
+static int launch_multi_t(const PairJobs& jobs, const PairHeader* hdr, dim3 grid, bool excl, int epi, hipStream_t st) {
+#define LVAE_MULTI(X, E) hipLaunchKernelGGL((pair_lse_multi_kernel<DP, NCB, WPS, X, E>), grid, dim3(256), 0, st, jobs, hdr)
+    switch (epi * 2 + (excl ? 1 : 0)) {
+        case 2: LVAE_MULTI(false, 1); break;
+        case 3: LVAE_MULTI(true, 1); break;
+        case 4: LVAE_MULTI(false, 2); break;
+        case 5: LVAE_MULTI(true, 2); break;
+        case 10: LVAE_MULTI(false, 5); break;
+        case 11: LVAE_MULTI(true, 5); break;
+        default: return lvae_set_error(LVAE_ERR_UNSUPPORTED, "multi-job launch: epilogue %d not instantiated", epi);
+    }
+#undef LVAE_MULTI
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+bool lvae_pair_multi_supported(int DP, int epi) { return (DP == 16 || DP == 32 || DP == 64) && (epi == 1 || epi == 2 || epi == 5); }
+
+int lvae_launch_pair_multi(int DP, const PairJobs& jobs, int njobs, const PairHeader* hdr, bool excl, int epi,
+                           hipStream_t st) {
+    int gx = 0, gy = 0;
+    for (int k = 0; k < njobs; ++k) {
+        const PairJob& J = jobs.j[k];
+        const int ncb = DP <= 32 ? 2 : 1;
+        if (J.cpad % (128 * ncb) != 0 || J.gx != (int)(J.cpad / (128 * ncb)) || J.gy < 1 || !J.colnorm)
+            return lvae_set_error(LVAE_ERR_INVALID, "multi-job launch: job %d does not match its plan", k);
+        if (J.gx > gx) gx = J.gx;
+        if (J.gy > gy) gy = J.gy;
+    }
+    const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)njobs);
+    switch (DP) {
+        case 16: return launch_multi_t<16, 2, 2>(jobs, hdr, grid, excl, epi, st);
+        case 32: return launch_multi_t<32, 2, 2>(jobs, hdr, grid, excl, epi, st);
+        case 64: return launch_multi_t<64, 1, 2>(jobs, hdr, grid, excl, epi, st);
+        default: return lvae_set_error(LVAE_ERR_UNSUPPORTED, "multi-job launch: plan dimension %d not instantiated", DP);
+    }
+}

@@ -47,6 +47,20 @@ struct PermArgs {
     int P;
 };
 
+// One kernel-sum job of a multi-job launch (pair_lse_multi_kernel): operands, partials and grid of one kernel matrix.
+struct PairJob {
+    const float* rfrag;
+    const float* rbias;
+    const float* cop;
+    const float* colnorm;
+    float2* partial;
+    int64_t nblk, blk_per_split, cpad, excl_offset;
+    int sym, gx, gy;
+};
+struct PairJobs {
+    PairJob j[3];
+};
+
 struct PairPlan {
     int64_t R;       // reduced axis length (posteriors for log q(z); samples for q_z_estimate)
     int64_t C;       // kept axis length (one output per element)
@@ -111,7 +125,9 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
         best = 1e300;
         int64_t ns_model = 1;
         for (int64_t c = 1; c <= max_ns; ++c) {
-            const int64_t wgs = groups * c;
+            // (sym: only the workgroups on and above the diagonal -- about half -- have work, the others exit at once;
+            //  with one resident round the fullest workgroup sets the time, so the range of a split must shrink)
+            const int64_t wgs = sym ? lvae_ceil_div(groups * c, 2) : groups * c;
             const double bps = (double)lvae_ceil_div(p.nblk, c);
             const double cost = wgs <= 256 ? 0.55 * bps + 4.0 : (double)lvae_ceil_div(wgs, slots) * (bps + 4.0);
             if (cost < best * 0.97) {

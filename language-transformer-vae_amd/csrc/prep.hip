@@ -278,6 +278,82 @@ prep_pair_kernel(const float* __restrict__ mu, const float* __restrict__ spread,
                             nullptr, nullptr, DC);
 }
 
+// Up to four kernel-sum operands in one launch (the POINT and SAMPLE forms of the two samples of an MMD): a workgroup
+// finds its job from the first-workgroup table, one 32-row block per workgroup.
+struct PrepJobs {
+    const float* x[4];
+    float* out[4];
+    float* bias[4];
+    int64_t n[4], npad[4], wg_begin[5];
+    int point[4];                  // 1: reduced-axis POINT rows (fragment-major, -2x, bias |x|^2); 0: kept-axis SAMPLE rows
+    int njobs;
+};
+
+__global__ void __launch_bounds__(1024)
+prep_ksum_multi_kernel(const PrepJobs J, int D, int DP, PairHeader* hdr) {
+    int k = 0;
+    while (k + 1 < J.njobs && (int64_t)blockIdx.x >= J.wg_begin[k + 1]) ++k;
+    const int64_t wg = (int64_t)blockIdx.x - J.wg_begin[k];
+    if (J.point[k])
+        prep_rows<3, true>(wg, 1, J.x[k], nullptr, 0, J.n[k], J.npad[k], D, DP, hdr, 1.0, J.out[k], J.bias[k], nullptr, 0);
+    else
+        prep_rows<4, false>(wg, 1, J.x[k], nullptr, 0, J.n[k], J.npad[k], D, DP, hdr, 1.0, J.out[k], J.bias[k], nullptr, 0);
+}
+
+int lvae_launch_prep_ksum_multi(const float* const* x, const int64_t* n, const int64_t* npad, float* const* out,
+                                float* const* bias, const int* point, int njobs, int D, int DP, PairHeader* hdr,
+                                hipStream_t st) {
+    PrepJobs J{};
+    J.njobs = njobs;
+    int64_t wg = 0;
+    for (int k = 0; k < njobs; ++k) {
+        J.x[k] = x[k]; J.out[k] = out[k]; J.bias[k] = bias[k]; J.n[k] = n[k]; J.npad[k] = npad[k]; J.point[k] = point[k];
+        J.wg_begin[k] = wg;
+        wg += npad[k] / 32;
+    }
+    J.wg_begin[njobs] = wg;
+    hipLaunchKernelGGL(prep_ksum_multi_kernel, dim3((unsigned)wg), dim3(32 * (DP / 4)), 0, st, J, D, DP, hdr);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
+// Totals of up to three sets of float64 kernel-sum partials [nsplit][cpad] in one launch (blockIdx.y = set), added into
+// out[set] -- which an earlier kernel of the call has zeroed (ksum_init_kernel).
+struct KsumSets {
+    const double* partial[3];
+    int nsplit[3];
+    int64_t cpad[3], C[3];
+};
+__global__ void __launch_bounds__(256) finalize_ksum_multi_kernel(const KsumSets S, double* __restrict__ out) {
+    const int y = blockIdx.y;
+    const double* __restrict__ partial = S.partial[y];
+    const int64_t cpad = S.cpad[y], C = S.C[y];
+    double acc = 0.0;
+    for (int k = 0; k < S.nsplit[y]; ++k)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < C; i += (int64_t)gridDim.x * 256)
+            acc += partial[k * cpad + i];
+    acc = wave_sum_d(acc);
+    __shared__ double sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&out[y], sm[0] + sm[1] + sm[2] + sm[3]);
+}
+
+int lvae_launch_finalize_ksum_multi(const double* const* partial, const int* nsplit, const int64_t* cpad, const int64_t* C,
+                                    int nsets, double* out, hipStream_t st) {
+    KsumSets S{};
+    int64_t cmax = 1;
+    for (int k = 0; k < nsets; ++k) {
+        S.partial[k] = partial[k]; S.nsplit[k] = nsplit[k]; S.cpad[k] = cpad[k]; S.C[k] = C[k];
+        if (C[k] > cmax) cmax = C[k];
+    }
+    int64_t blocks = lvae_ceil_div(cmax, 256);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(finalize_ksum_multi_kernel, dim3((unsigned)blocks, (unsigned)nsets), dim3(256), 0, st, S, out);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
 // Direct-path parameters only (used when the MFMA path is not available for this D).
 // gate_hdr != NULL: only when the conditioning estimate selects the direct path (cond > cond_limit).
 __global__ void prep_dparams_kernel(const float* __restrict__ mu, const float* __restrict__ spread,
