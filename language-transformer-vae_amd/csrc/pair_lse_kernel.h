@@ -497,7 +497,7 @@ pair_lse_body(const float* __restrict__ rfrag, const float* __restrict__ rbias,
     // row biases as its C operand) while the epilogue of `prev` issues in their shadow.  Everything is
     // pinned in program order (sched_barrier) so the compiler cannot bunch the epilogue up.
     int t_lin = 0;                                         // chunks consumed so far by this wave
-    auto run_block = [&](f32x16 (&acc)[NCB], const f32x16 (&prev)[NCB], int64_t blk, bool with_epi) {
+    auto run_block = [&](f32x16 (&acc)[NCB], const f32x16 (&prev)[NCB], int64_t blk, bool with_epi) __attribute__((always_inline)) {
         const f32x16 cv = c_pre;
         f32x16 cvm[EXCL ? NCB : 1];
         if constexpr (EXCL) {
@@ -606,7 +606,7 @@ pair_lse_body(const float* __restrict__ rfrag, const float* __restrict__ rbias,
         }
         }
     };
-    auto drain = [&](const f32x16 (&prev)[NCB]) {
+    auto drain = [&](const f32x16 (&prev)[NCB]) __attribute__((always_inline)) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
