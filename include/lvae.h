@@ -87,10 +87,14 @@ int lvae_log_qz_noalloc_f32(const float* z, const float* mu, const float* spread
  * training objectives, loss_and_optimisation.py:925-1018 via modules/encoder.py:102-107).
  * Inputs: the forward inputs (logvar only), log_norm, the forward result log_qz [M] (needed with g_log_qz),
  * and the upstream gradients g_log_qz [M] (on log_qz) and/or g_prod_marg [M] (on log_qz_prod_marg); either
- * may be NULL.  Outputs (each may be NULL): d_z [M,D], d_mu [N,D], d_logvar [N,D].  Sized for training-time
- * batches.  D <= 64: the softmax weights are recomputed in registers, nothing of size M x N is stored.
- * D > 64: the joint weights are read from an explicit N x M matrix of pair densities held in the workspace
- * (M * N <= 2^28, LVAE_ERR_UNSUPPORTED beyond). */
+ * may be NULL.  Outputs (each may be NULL): d_z [M,D], d_mu [N,D], d_logvar [N,D].  Nothing of size M x N is
+ * stored for D <= 128 when only g_log_qz is given: the softmax weights are recomputed tile by tile on the fp32
+ * matrix cores and contracted with thin feature matrices in registers (pair_grad_mfma.hip; any M, N), behind a
+ * device-side conditioning gate with the vector-ALU sweeps (exact differences, D <= 64: weights recomputed in
+ * registers) as the other branch.  The weights of a sample are renormalised by their own sum, so the caller's
+ * log_qz only has to be good to ~1e-2.  With g_prod_marg the vector-ALU sweeps run.  D > 64 on the vector ALU
+ * (g_prod_marg given, or D > 128) reads the joint weights from an explicit N x M matrix of pair densities held
+ * in the workspace (M * N <= 2^28, LVAE_ERR_UNSUPPORTED beyond). */
 int lvae_log_qz_bwd_workspace_bytes(int64_t M, int64_t N, int D, int prod_marginals, int64_t* out_bytes);
 int lvae_log_qz_bwd_f32(const float* z, const float* mu, const float* logvar, int64_t M, int64_t N, int D,
                         float log_norm, const float* log_qz, const float* g_log_qz, const float* g_prod_marg,

@@ -96,11 +96,13 @@ int lvae_launch_grad_records(const float* z, const float* log_qz, float log_norm
                              hipStream_t st);
 int lvae_launch_grad_sample(const float* z, const float* dparams, const float* log_qz, float log_norm,
                             const float* g, const float* h, const float* lse2, int64_t M, int64_t N, int D,
-                            int DC, int nsplit, int64_t rows_per_split, float* partial_dz, hipStream_t st);
+                            int DC, int nsplit, int64_t rows_per_split, float* partial_dz, hipStream_t st,
+                            const PairHeader* gate_hdr = nullptr, float cond_limit = 0.f);
 int lvae_launch_grad_posterior(const float* dparams, const float* rec, bool pm, int64_t M, int64_t N, int DC,
-                               int nsplit, int64_t rows_per_split, float* partial_dp, hipStream_t st);
+                               int nsplit, int64_t rows_per_split, float* partial_dp, hipStream_t st,
+                               const PairHeader* gate_hdr = nullptr, float cond_limit = 0.f);
 int lvae_launch_grad_reduce(const float* partial, int nsplit, int64_t rows, int stride, int off, int D,
-                            float* out, hipStream_t st);
+                            float* out, hipStream_t st, const PairHeader* gate_hdr = nullptr, float cond_limit = 0.f);
 int lvae_launch_sample_ll_bwd(const float* z, const float* mu, const float* logvar, const float* g, int g_elem,
                               int64_t B, int64_t K, int D, float* d_z, float* d_mu, float* d_logvar,
                               hipStream_t st);
@@ -115,7 +117,12 @@ int lvae_launch_lse_rebase(const float* max_a, const float* sum_a, const float* 
                            hipStream_t st);
 int lvae_launch_grad_wide(const float* z, const float* dparams, const float* P, const float* log_qz, float log_norm,
                           const float* g, const float* h, const float* lse2, int64_t M, int64_t N, int D, int DC,
-                          float* d_z, float* d_mu, float* d_logvar, hipStream_t st);
+                          float* d_z, float* d_mu, float* d_logvar, hipStream_t st,
+                          const PairHeader* gate_hdr = nullptr, float cond_limit = 0.f);
+int lvae_launch_bwd_mfma(const BwdMfmaLayout& L, void* ws, const float* z, const float* mu, const float* logvar,
+                         int64_t M, int64_t N, int D, float log_norm, const float* log_qz, const float* g,
+                         PairHeader* hdr, float cond_limit, float* d_z, float* d_mu, float* d_logvar, hipStream_t st);
+BwdMfmaLayout lvae_bwd_mfma_layout(int64_t M, int64_t N, int D);
 int lvae_launch_ksum_wide(const float* a, const float* b, int64_t na, int64_t nb, int D, const PairHeader* hdr,
                           bool excl, int64_t excl_offset, int nsplit, int64_t cpad, double* partial,
                           hipStream_t st);
@@ -584,10 +591,15 @@ struct GradLayout {
     PairPlan p;
     int nsA, nsB;                 // splits of the looped axis: posteriors (sample sweep), samples (posterior sweep)
     int64_t rowsA, rowsB;
-    size_t off_lse, off_rec, off_pdz, off_pdp, off_pmat, total;
+    BwdMfmaLayout mf;             // matrix-core sweeps (joint density only, D <= 128)
+    size_t off_lse, off_rec, off_pdz, off_pdp, off_pmat, off_mfma, off_lqacc, total;
 };
 #define LVAE_GRAD_WIDE_MAX_PAIRS (1LL << 28)     // D > 64: the explicit N x M pair matrix is capped at 1 GiB
-
+// Largest conditioning estimate (pair_grad_mfma.hip: the largest eight-dimension group of cancelling terms, times
+// sqrt(groups)) for which the matrix-core backward holds 1e-4 relative on the gradients.  Measured against float64
+// (tools/diag_bwd.py): d z and d mu stay below 3e-6 up to an estimate of 1e5; d logvar, whose second-moment sums
+// cancel like the expansion itself, reaches 2e-5 at 1e4-3e4 and 1e-4..2e-4 at 6e4-2e5.
+#define LVAE_BWD_COND_LIMIT 2.0e4f
 static int grad_splits(int64_t kept, int64_t looped, int64_t* rows) {
     const int64_t waves = lvae_ceil_div(kept, 64);
     int64_t ns = lvae_ceil_div(2048, waves);
@@ -610,8 +622,15 @@ static GradLayout grad_layout(int64_t M, int64_t N, int D, bool pm) {
     g.off_rec = o; o = lvae_align256(o + (size_t)M * (2 * DC + 4) * sizeof(float));
     g.off_pdz = o; o = lvae_align256(o + (size_t)g.nsA * M * DC * sizeof(float));
     g.off_pdp = o; o = lvae_align256(o + (size_t)g.nsB * N * 2 * DC * sizeof(float));
+    g.off_lqacc = o; o = lvae_align256(o + (size_t)g.p.cpad * sizeof(float));
     g.off_pmat = o;
     if (D > 64 && M * N <= LVAE_GRAD_WIDE_MAX_PAIRS) o = lvae_align256(o + (size_t)M * N * sizeof(float));
+    g.off_mfma = o;
+    g.mf = BwdMfmaLayout{};
+    if (!pm) {
+        g.mf = lvae_bwd_mfma_layout(M, N, D);
+        if (g.mf.DP) o = lvae_align256(o + g.mf.total);
+    }
     g.total = o;
     return g;
 }
@@ -631,64 +650,98 @@ extern "C" int lvae_log_qz_bwd_f32(const float* z, const float* mu, const float*
     int rc = check_pair_shapes(z, mu, logvar, LVAE_SPREAD_LOGVAR, M, N, D);
     if (rc) return rc;
     LVAE_CHECK_ARG(g_log_qz || g_prod_marg, "at least one upstream gradient is required");
-    if (D > 64 && (M * N > LVAE_GRAD_WIDE_MAX_PAIRS || M >= (1LL << 31) || N >= (1LL << 31)))
-        return lvae_set_error(LVAE_ERR_UNSUPPORTED,
-                              "the backward pass for D > 64 keeps an explicit N x M pair matrix and is sized for "
-                              "training batches: M * N <= 2^28 (got M=%lld, N=%lld)", (long long)M, (long long)N);
     LVAE_CHECK_ARG(!g_log_qz || log_qz, "log_qz (the forward result) is required with g_log_qz");
     LVAE_CHECK_ARG(d_z || d_mu || d_logvar, "at least one output gradient is required");
     const bool pm = g_prod_marg != nullptr;
+    // Path: the joint-density gradient runs on the matrix cores (D <= 128), behind a device-side conditioning gate
+    // when the vector-ALU form can serve the shape as well (both are launched, one exits); gradients through the
+    // prod-marginals term take the vector-ALU form.  LVAE_BWD_PATH = valu | mfma forces one (tests, benchmarks;
+    // mfma: ungated).
+    const bool mfma_ok = !pm && lvae_pad_dim(D) != 0;
+    const bool valu_ok = D <= 64 || M * N <= LVAE_GRAD_WIDE_MAX_PAIRS;
+    const char* env = getenv("LVAE_BWD_PATH");
+    bool use_mfma = mfma_ok;      // (at every size: 50 vs 185 us at 512^2, D = 32; 86 vs 335 us at 2,048^2)
+    bool use_valu = !use_mfma || valu_ok;
+    if (env && !strcmp(env, "valu")) { use_mfma = false; use_valu = true; }
+    if (env && !strcmp(env, "mfma") && mfma_ok) { use_mfma = true; use_valu = false; }
+    if (use_valu && !valu_ok)
+        return lvae_set_error(LVAE_ERR_UNSUPPORTED,
+                              "the backward pass for D > 64 with prod-marginals gradients (or D > 128) keeps an explicit "
+                              "N x M pair matrix and is sized for training batches: M * N <= 2^28 (got M=%lld, N=%lld)",
+                              (long long)M, (long long)N);
     const GradLayout g = grad_layout(M, N, D, pm);
     rc = check_ws(ws, ws_bytes, g.total);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const PairPlan& p = g.p;
     char* base = (char*)ws;
+    PairHeader* hdr = (PairHeader*)(base + p.off_hdr);
+    const PairHeader* gate = nullptr;        // non-NULL: the vector-ALU kernels run iff cond > LVAE_BWD_COND_LIMIT
+    if (use_mfma) {
+        LVAE_HIP(hipMemsetAsync(hdr, 0, sizeof(PairHeader), st));
+        rc = lvae_launch_colsum(mu, N, D, hdr, st);
+        if (rc) return rc;
+        rc = lvae_launch_bwd_mfma(g.mf, base + g.off_mfma, z, mu, logvar, M, N, D, log_norm, log_qz, g_log_qz, hdr,
+                                  use_valu ? LVAE_BWD_COND_LIMIT : -1.0f, d_z, d_mu, d_logvar, st);
+        if (rc || !use_valu) return rc;
+        gate = hdr;
+    }
     float* dparams = (float*)(base + p.off_dparams);
     float* lse2 = pm ? (float*)(base + g.off_lse) : nullptr;
     float* rec = (float*)(base + g.off_rec);
     float* pdz = (float*)(base + g.off_pdz);
     float* pdp = (float*)(base + g.off_pdp);
-    rc = lvae_launch_prep_dparams(mu, logvar, LVAE_SPREAD_LOGVAR, N, D, p.DC, dparams, nullptr, 0.f, st);
+    rc = lvae_launch_prep_dparams(mu, logvar, LVAE_SPREAD_LOGVAR, N, D, p.DC, dparams, gate, LVAE_BWD_COND_LIMIT, st);
     if (rc) return rc;
-    if (pm) {   // per-(sample, dimension) logsumexp over the posteriors: the forward prod-marginals sweep
-        rc = lvae_launch_pair_direct(p, false, true, z, dparams, nullptr, (float2*)(base + p.off_dpartial_pm),
-                                     (int*)(base + p.off_dflags), (const PairHeader*)(base + p.off_hdr), -1.f, 0,
-                                     0, 0, st);
-        if (rc) return rc;
+    // One forward sweep in the direct form (exact differences) ahead of the gradient sweeps: the per-(sample, dimension)
+    // logsumexp the prod-marginals weights need, and the joint logsumexp L_i again -- the caller's log_qz may come
+    // from the matrix-core expansion, whose absolute error (a few 1e-4 at D ~ 100) would be the RELATIVE error of
+    // every weight exp(v_ij - L_i); recomputed here the weights of a sample sum to one to fp32 rounding.
+    const float gate_limit = gate ? LVAE_BWD_COND_LIMIT : -1.0f;
+    float* lq_acc = (float*)(base + g.off_lqacc);
+    rc = lvae_launch_pair_direct(p, g_log_qz != nullptr, pm, z, dparams, (float2*)(base + p.off_dpartial),
+                                 (float2*)(base + p.off_dpartial_pm), (int*)(base + p.off_dflags), hdr, gate_limit, 1,
+                                 0, 0, st);
+    if (rc) return rc;
+    if (pm) {
         rc = lvae_launch_finalize_pm_lse((const float2*)(base + p.off_dpartial_pm), p.dsplit, p.cpad, M, p.DC,
                                          lse2, st);
         if (rc) return rc;
     }
+    if (g_log_qz) {
+        rc = lvae_launch_finalize((const float2*)(base + p.off_dpartial), p.dsplit, p.cpad, M, nullptr, log_norm, lq_acc,
+                                  nullptr, nullptr, hdr, gate_limit, 1, 0, nullptr, nullptr, 128 * p.NCB, st);
+        if (rc) return rc;
+    }
     const float* gq = g_log_qz;
-    const float* lq = g_log_qz ? log_qz : nullptr;
+    const float* lq = g_log_qz ? lq_acc : nullptr;
     if (D > 64) {
         float* pmat = (float*)(base + g.off_pmat);
-        if (gq) {
+        if (gq) {   // (no gate of its own: a gated wide problem pays for the M x N writes whichever path is selected)
             rc = lvae_launch_pair_matrix(mu, logvar, LVAE_SPREAD_LOGVAR, z, N, M, D, 0, nullptr, pmat, st);
             if (rc) return rc;
         }
         return lvae_launch_grad_wide(z, dparams, pmat, lq, log_norm, gq, g_prod_marg, lse2, M, N, D, p.DC, d_z, d_mu,
-                                     d_logvar, st);
+                                     d_logvar, st, gate, LVAE_BWD_COND_LIMIT);
     }
     if (d_z) {
         rc = lvae_launch_grad_sample(z, dparams, lq, log_norm, gq, g_prod_marg, lse2, M, N, D, p.DC, g.nsA,
-                                     g.rowsA, pdz, st);
+                                     g.rowsA, pdz, st, gate, LVAE_BWD_COND_LIMIT);
         if (rc) return rc;
-        rc = lvae_launch_grad_reduce(pdz, g.nsA, M, p.DC, 0, D, d_z, st);
+        rc = lvae_launch_grad_reduce(pdz, g.nsA, M, p.DC, 0, D, d_z, st, gate, LVAE_BWD_COND_LIMIT);
         if (rc) return rc;
     }
     if (d_mu || d_logvar) {
         rc = lvae_launch_grad_records(z, lq, log_norm, gq, g_prod_marg, lse2, M, D, p.DC, rec, st);
         if (rc) return rc;
-        rc = lvae_launch_grad_posterior(dparams, rec, pm, M, N, p.DC, g.nsB, g.rowsB, pdp, st);
+        rc = lvae_launch_grad_posterior(dparams, rec, pm, M, N, p.DC, g.nsB, g.rowsB, pdp, st, gate, LVAE_BWD_COND_LIMIT);
         if (rc) return rc;
         if (d_mu) {
-            rc = lvae_launch_grad_reduce(pdp, g.nsB, N, 2 * p.DC, 0, D, d_mu, st);
+            rc = lvae_launch_grad_reduce(pdp, g.nsB, N, 2 * p.DC, 0, D, d_mu, st, gate, LVAE_BWD_COND_LIMIT);
             if (rc) return rc;
         }
         if (d_logvar) {
-            rc = lvae_launch_grad_reduce(pdp, g.nsB, N, 2 * p.DC, p.DC, D, d_logvar, st);
+            rc = lvae_launch_grad_reduce(pdp, g.nsB, N, 2 * p.DC, p.DC, D, d_logvar, st, gate, LVAE_BWD_COND_LIMIT);
             if (rc) return rc;
         }
     }

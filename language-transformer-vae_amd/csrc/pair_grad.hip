@@ -67,7 +67,9 @@ __global__ void __launch_bounds__(256)
 pair_grad_sample_kernel(const float* __restrict__ z, const float* __restrict__ dparams,
                         const float* __restrict__ log_qz, float log_norm, const float* __restrict__ g,
                         const float* __restrict__ h, const float* __restrict__ lse2, int64_t M, int64_t N,
-                        int D, int DC, int64_t rows_per_split, float* __restrict__ partial_dz) {
+                        int D, int DC, int64_t rows_per_split, float* __restrict__ partial_dz,
+                        const PairHeader* __restrict__ gate_hdr, float cond_limit) {
+    if (gate_hdr && !(__uint_as_float(gate_hdr->cond_bits) > cond_limit)) return;
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = col < M ? col : M - 1;
     float zr[DCT], dz[DCT], ls[PM ? DCT : 1];
@@ -115,7 +117,9 @@ pair_grad_sample_kernel(const float* __restrict__ z, const float* __restrict__ d
 template <int DCT, bool PM>
 __global__ void __launch_bounds__(256)
 pair_grad_posterior_kernel(const float* __restrict__ dparams, const float* __restrict__ rec, int64_t M,
-                           int64_t N, int DC, int64_t rows_per_split, float* __restrict__ partial_dp) {
+                           int64_t N, int DC, int64_t rows_per_split, float* __restrict__ partial_dp,
+                           const PairHeader* __restrict__ gate_hdr, float cond_limit) {
+    if (gate_hdr && !(__uint_as_float(gate_hdr->cond_bits) > cond_limit)) return;
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t j = col < N ? col : N - 1;
     const int RS = 2 * DC + GRAD_REC_EXTRA;
@@ -169,7 +173,8 @@ __global__ void __launch_bounds__(256)
 grad_wide_sample_kernel(const float* __restrict__ z, const float* __restrict__ dparams, const float* __restrict__ P,
                         const float* __restrict__ log_qz, float log_norm, const float* __restrict__ g,
                         const float* __restrict__ h, const float* __restrict__ lse2, int64_t M, int64_t N, int D,
-                        int DC, float* __restrict__ d_z) {
+                        int DC, float* __restrict__ d_z, const PairHeader* __restrict__ gate_hdr, float cond_limit) {
+    if (gate_hdr && !(__uint_as_float(gate_hdr->cond_bits) > cond_limit)) return;
     const int d = blockIdx.y * 256 + threadIdx.x;
     const int64_t i = blockIdx.x;
     if (d >= D) return;
@@ -197,7 +202,9 @@ grad_wide_posterior_kernel(const float* __restrict__ z, const float* __restrict_
                            const float* __restrict__ P, const float* __restrict__ log_qz, float log_norm,
                            const float* __restrict__ g, const float* __restrict__ h,
                            const float* __restrict__ lse2, int64_t M, int64_t N, int D, int DC,
-                           float* __restrict__ d_mu, float* __restrict__ d_logvar) {
+                           float* __restrict__ d_mu, float* __restrict__ d_logvar,
+                           const PairHeader* __restrict__ gate_hdr, float cond_limit) {
+    if (gate_hdr && !(__uint_as_float(gate_hdr->cond_bits) > cond_limit)) return;
     const int d = blockIdx.y * 256 + threadIdx.x;
     const int64_t j = blockIdx.x;
     if (d >= D) return;
@@ -219,14 +226,15 @@ grad_wide_posterior_kernel(const float* __restrict__ z, const float* __restrict_
 
 int lvae_launch_grad_wide(const float* z, const float* dparams, const float* P, const float* log_qz, float log_norm,
                           const float* g, const float* h, const float* lse2, int64_t M, int64_t N, int D, int DC,
-                          float* d_z, float* d_mu, float* d_logvar, hipStream_t st) {
+                          float* d_z, float* d_mu, float* d_logvar, hipStream_t st, const PairHeader* gate_hdr,
+                          float cond_limit) {
     const unsigned dy = (unsigned)lvae_ceil_div(D, 256);
     if (d_z)
         hipLaunchKernelGGL(grad_wide_sample_kernel, dim3((unsigned)M, dy), dim3(256), 0, st, z, dparams, P, log_qz,
-                           log_norm, g, h, lse2, M, N, D, DC, d_z);
+                           log_norm, g, h, lse2, M, N, D, DC, d_z, gate_hdr, cond_limit);
     if (d_mu || d_logvar)
         hipLaunchKernelGGL(grad_wide_posterior_kernel, dim3((unsigned)N, dy), dim3(256), 0, st, z, dparams, P, log_qz,
-                           log_norm, g, h, lse2, M, N, D, DC, d_mu, d_logvar);
+                           log_norm, g, h, lse2, M, N, D, DC, d_mu, d_logvar, gate_hdr, cond_limit);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }
@@ -234,7 +242,8 @@ int lvae_launch_grad_wide(const float* z, const float* dparams, const float* P, 
 // out[row][d] = sum_k partial[k][row][off + d]   (d < D; partial rows are `stride` floats wide)
 __global__ void __launch_bounds__(256)
 grad_reduce_kernel(const float* __restrict__ partial, int nsplit, int64_t rows, int stride, int off, int D,
-                   float* __restrict__ out) {
+                   float* __restrict__ out, const PairHeader* __restrict__ gate_hdr, float cond_limit) {
+    if (gate_hdr && !(__uint_as_float(gate_hdr->cond_bits) > cond_limit)) return;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= rows * D) return;
     const int64_t row = idx / D;
@@ -265,12 +274,13 @@ int lvae_launch_grad_records(const float* z, const float* log_qz, float log_norm
 
 int lvae_launch_grad_sample(const float* z, const float* dparams, const float* log_qz, float log_norm,
                             const float* g, const float* h, const float* lse2, int64_t M, int64_t N, int D,
-                            int DC, int nsplit, int64_t rows_per_split, float* partial_dz, hipStream_t st) {
+                            int DC, int nsplit, int64_t rows_per_split, float* partial_dz, hipStream_t st,
+                            const PairHeader* gate_hdr, float cond_limit) {
     const dim3 grid((unsigned)lvae_ceil_div(M, 256), (unsigned)nsplit);
     const bool pm = h != nullptr;
 #define LVAE_GS(DCT, P)                                                                                 \
     hipLaunchKernelGGL((pair_grad_sample_kernel<DCT, P>), grid, dim3(256), 0, st, z, dparams, log_qz,    \
-                       log_norm, g, h, lse2, M, N, D, DC, rows_per_split, partial_dz)
+                       log_norm, g, h, lse2, M, N, D, DC, rows_per_split, partial_dz, gate_hdr, cond_limit)
     if (DC == 16) { if (pm) LVAE_GS(16, true); else LVAE_GS(16, false); }
     else if (DC == 32) { if (pm) LVAE_GS(32, true); else LVAE_GS(32, false); }
     else if (DC == 64) { if (pm) LVAE_GS(64, true); else LVAE_GS(64, false); }
@@ -281,11 +291,12 @@ int lvae_launch_grad_sample(const float* z, const float* dparams, const float* l
 }
 
 int lvae_launch_grad_posterior(const float* dparams, const float* rec, bool pm, int64_t M, int64_t N, int DC,
-                               int nsplit, int64_t rows_per_split, float* partial_dp, hipStream_t st) {
+                               int nsplit, int64_t rows_per_split, float* partial_dp, hipStream_t st,
+                               const PairHeader* gate_hdr, float cond_limit) {
     const dim3 grid((unsigned)lvae_ceil_div(N, 256), (unsigned)nsplit);
 #define LVAE_GP(DCT, P)                                                                                 \
     hipLaunchKernelGGL((pair_grad_posterior_kernel<DCT, P>), grid, dim3(256), 0, st, dparams, rec, M, N, \
-                       DC, rows_per_split, partial_dp)
+                       DC, rows_per_split, partial_dp, gate_hdr, cond_limit)
     if (DC == 16) { if (pm) LVAE_GP(16, true); else LVAE_GP(16, false); }
     else if (DC == 32) { if (pm) LVAE_GP(32, true); else LVAE_GP(32, false); }
     else if (DC == 64) { if (pm) LVAE_GP(64, true); else LVAE_GP(64, false); }
@@ -296,9 +307,9 @@ int lvae_launch_grad_posterior(const float* dparams, const float* rec, bool pm, 
 }
 
 int lvae_launch_grad_reduce(const float* partial, int nsplit, int64_t rows, int stride, int off, int D,
-                            float* out, hipStream_t st) {
+                            float* out, hipStream_t st, const PairHeader* gate_hdr, float cond_limit) {
     hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)lvae_ceil_div(rows * D, 256)), dim3(256), 0, st,
-                       partial, nsplit, rows, stride, off, D, out);
+                       partial, nsplit, rows, stride, off, D, out, gate_hdr, cond_limit);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }

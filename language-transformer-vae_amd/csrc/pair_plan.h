@@ -61,6 +61,15 @@ struct PairJobs {
     PairJob j[3];
 };
 
+// Workspace region and grid of the MFMA backward of log q(z) (pair_grad_mfma.hip).
+struct BwdMfmaLayout {
+    int DP;                        // 0: unsupported (D > 128)
+    int64_t cpad_i, cpad_j;        // samples / posteriors padded to the workgroup tile (128)
+    int ns_a, ns_b;                // splits of the streamed axis: posteriors (sweep A), samples (sweep B)
+    int64_t bps_a, bps_b;          // 32-row blocks per split
+    size_t off_recj, off_reci, off_colj, off_coli, off_cbj, off_cbi, off_pa, off_pb, off_w0, off_w0a, off_gs, off_cgj, total;
+};
+
 struct PairPlan {
     int64_t R;       // reduced axis length (posteriors for log q(z); samples for q_z_estimate)
     int64_t C;       // kept axis length (one output per element)
