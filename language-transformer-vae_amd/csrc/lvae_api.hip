@@ -426,21 +426,20 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     }
     if (need_direct) {
         const bool djoint = want_joint && joint_path != LVAE_PATH_MFMA;
-        // The prod-marginals polynomial on the bf16 matrix pipe (D <= 64; three bf16 limbs per value, fp32-equivalent):
-        // unconditionally on the opt-in bf16x3 path; in AUTO mode behind the same device-side conditioning test as
-        // the joint density (the packed-fp32 direct form runs with the opposite gate), from LVAE_PM_BX_MIN_PAIRS on.
+        // The prod-marginals polynomial on the bf16 matrix pipe (D <= 64; three bf16 limbs per value, fp32-equivalent),
+        // always behind the device-side conditioning test (its expansion cancels like the joint one; the packed-fp32
+        // direct form runs with the opposite gate): on the opt-in bf16x3 path at every size, in AUTO mode from
+        // LVAE_PM_BX_MIN_PAIRS on.
         const bool pm_bx_ok = with_pm && p.DP && lvae_pm_bx_supported(p.DC);
-        const bool pm_bx_forced = bx && pm_bx_ok;
-        const bool pm_bx_auto = !bx && pm_bx_ok && gated && need_mfma && (double)N * (double)M >= LVAE_PM_BX_MIN_PAIRS;
-        if (pm_bx_forced || pm_bx_auto) {
+        const bool pm_bx = pm_bx_ok && (bx || (gated && need_mfma && (double)N * (double)M >= LVAE_PM_BX_MIN_PAIRS));
+        if (pm_bx) {
             rc = lvae_launch_pm_bx(p, z, mu, spread, spread_kind, hdr, base + p.off_pmbx_a, base + p.off_pmbx_b,
-                                   dpartial_pm, (int*)(base + p.off_dflags), pm_bx_auto ? LVAE_COND_LIMIT : -1.0f, st);
+                                   dpartial_pm, (int*)(base + p.off_dflags), LVAE_COND_LIMIT, st);
             if (rc) return rc;
         }
         rc = lvae_launch_pair_direct(p, djoint, with_pm, z, dparams, dpartial, dpartial_pm,
                                      (int*)(base + p.off_dflags), hdr, limit, 1,
-                                     exclude_diag, diag_offset, st, pm_bx_forced,
-                                     pm_bx_auto ? LVAE_COND_LIMIT : -1.0f);
+                                     exclude_diag, diag_offset, st, false, pm_bx ? LVAE_COND_LIMIT : -1.0f);
         if (rc) return rc;
     }
     if (prof_stop) prof_mark(st, prof_stop);

@@ -63,7 +63,7 @@ def prepare_pareto_dict(config):
     return {key: [] for flag, key in PARETO_KEYS if getattr(config, flag, False)}
 
 
-def determine_pareto_checkpoint(val_epoch_stats, epoch_pareto_effiency_dict, epoch, logging=False,
+def determine_pareto_checkpoint(val_epoch_stats, epoch_pareto_effiency_dict, epoch, logging=True,
                                 decoder_only=False):
     """utils_train.py:464-516: append this epoch's summary of every tracked metric and return the dict and
     the list of Pareto-efficient epochs.  "-D_ks" is the negated KS distance between the epoch's two IW-LL
@@ -71,9 +71,10 @@ def determine_pareto_checkpoint(val_epoch_stats, epoch_pareto_effiency_dict, epo
     instead of being appended (:499), so the point matrix at :502 cannot be built and the call raises
     IndexError, there and here (train.py:228: "not using D_ks for pareto checkpointing anymore"); use
     ``ks_2samp`` directly.
-    ``logging`` (wandb in the reference, :510-514) is not provided."""
-    if logging:
-        raise NotImplementedError("wandb logging is outside this path")
+    ``logging`` (default True as in the reference, :464): the record {"pareto epoch": epoch, "pareto <metric>":
+    this epoch's value} of :510-514 goes to ``wandb.log`` when wandb is importable (the reference's sink; it is
+    not part of this image), otherwise to the ``lvae.pareto`` Python logger; a callable receives the record
+    itself.  "Efficient epochs: [...]" is printed as at :508."""
     metrics = list(epoch_pareto_effiency_dict.keys())
     for metric in metrics:
         if metric in ("kl_analytical", "iw_ll_p_w", "iw_ll_x_gen_p_w", "elbo"):
@@ -87,4 +88,18 @@ def determine_pareto_checkpoint(val_epoch_stats, epoch_pareto_effiency_dict, epo
             epoch_pareto_effiency_dict[metric] = np.float64(-d)
     points = np.asarray([[epoch_pareto_effiency_dict[m][i] for m in metrics] for i in range(epoch + 1)])
     efficient_epochs = np.where(is_pareto_efficient_simple(points))[0].tolist()
+    print("Efficient epochs:", efficient_epochs)
+    if logging:
+        record = {"pareto epoch": epoch}
+        for m in metrics:
+            record[f"pareto {m}"] = epoch_pareto_effiency_dict[m][-1]
+        if callable(logging):
+            logging(record)
+        else:
+            try:
+                import wandb
+                wandb.log(record)
+            except ImportError:
+                import logging as _pylog
+                _pylog.getLogger("lvae.pareto").info("%s", record)
     return epoch_pareto_effiency_dict, efficient_epochs

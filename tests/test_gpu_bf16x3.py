@@ -96,6 +96,25 @@ def test_bf16x3_prod_marginals_on_the_matrix_pipe():
         assert float((lqpm - lqpm1).abs().max()) <= 2e-3
 
 
+def test_bf16x3_prod_marginals_ill_conditioned_takes_the_direct_form():
+    """Posteriors a few thousand standard deviations from the centre: the per-dimension polynomial cancels beyond
+    what three limbs hold, the device-side conditioning test (the one AUTO uses) sends the prod-marginals sweep to
+    the packed-fp32 direct form, and the opt-in path still matches the float64 oracle."""
+    from lvae import estimators as E
+    rng = np.random.default_rng(8)
+    N_, M_, D = 600, 700, 32
+    mu = (3.0 * rng.standard_normal((N_, D))).astype(np.float32)
+    logvar = (0.3 * rng.standard_normal((N_, D)) - 14.0).astype(np.float32)        # sigma ~ 1e-3
+    src = rng.integers(0, N_, M_)
+    z = (mu[src] + rng.standard_normal((M_, D)) * np.exp(0.5 * logvar[src])).astype(np.float32)
+    _, refpm = onp.approximate_log_q_z(mu, logvar, z, method="all", prod_marginals=True, reduce_mean=False)
+    lq, lqpm = E.approximate_log_q_z(dev(mu), dev(logvar), dev(z), method="all", prod_marginals=True, reduce_mean=False,
+                                     path=BX)
+    scale = float(np.abs(refpm).max())
+    np.testing.assert_allclose(lqpm.cpu().numpy(), refpm, rtol=1e-4, atol=1e-4 * scale)
+    assert rel(lqpm.double().mean(), refpm.mean()) < 1e-4
+
+
 @pytest.mark.parametrize("n,D", [(65536, 32), (32768, 64)])
 def test_bf16x3_matches_fp32_path_at_full_size(n, D):
     """C2 (N = M = 65,536, D = 32) and a D = 64 case: per-sample agreement with the fp32 MFMA path."""

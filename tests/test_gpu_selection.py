@@ -85,7 +85,11 @@ def test_determine_pareto_checkpoint():
         stats_e = {"kl_analytical": rng.random(10) + 0.1 * epoch, "iw_ll_p_w": -100 + rng.random(10),
                    "reconstruction_loss": 90 - epoch + rng.random(10), "tts_mmd_loss": rng.random(10) * 0.01}
         epochs.append(stats_e)
-        track, eff = determine_pareto_checkpoint(stats_e, track, epoch)
+        records = []
+        track, eff = determine_pareto_checkpoint(stats_e, track, epoch, logging=records.append)
+        # the record of utils_train.py:510-514 ("pareto epoch" + this epoch's value of every tracked metric)
+        assert records == [dict({"pareto epoch": epoch}, **{f"pareto {m}": track[m][-1] for m in track})]
+    assert determine_pareto_checkpoint.__defaults__[0] is True        # the reference's default (:464)
     pts = np.array([[np.mean(e["kl_analytical"]), np.mean(e["iw_ll_p_w"]), -np.mean(e["reconstruction_loss"]),
                      -np.mean(e["tts_mmd_loss"])] for e in epochs])
     assert eff == np.where(onp.is_pareto_efficient(pts))[0].tolist()
