@@ -10,7 +10,7 @@ TAG=${1:-r01}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+BENCH="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-side-runs"
 step() { echo "== $1" | tee -a "$OUT/progress.log"; }
 
 step "kernel trace of bench.py"
@@ -33,4 +33,10 @@ step "kernel trace of the split-bf16 comparison"
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_bf16x3" -o p -- python3 $R/tools/bench_bf16x3.py > "$OUT/bf16x3.log" 2>&1 || exit 1
 step "PMC SQ + clock of the split-bf16 pair kernel"
 timeout -s KILL 150 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_bf16x3" -o p -- python3 $R/tools/run_path.py 3 65536 32 20 > "$OUT/pmc_bf16x3.log" 2>&1 || exit 1
+step "kernel trace of the matrix-core backward"
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_bwd" -o p -- python3 $R/tools/bench_bwd.py 16384,16384,32 16384,16384,64 16384,16384,128 65536,65536,32 > "$OUT/bwd.log" 2>&1 || exit 1
+step "IW, small problems, training tail (no trace)"
+timeout -k 10 200 python3 $R/tools/bench_iw.py > "$OUT/iw.log" 2>&1 || exit 1
+timeout -k 10 200 python3 $R/tools/bench_small.py > "$OUT/small.log" 2>&1 || exit 1
+timeout -k 10 200 python3 $R/tools/bench_train_tail.py > "$OUT/train_tail.log" 2>&1 || exit 1
 step "done"
