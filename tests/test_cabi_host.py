@@ -150,10 +150,20 @@ def test_grid_quantisation_of_multi_gpu_shapes():
 
 
 def test_committed_bench_line_has_the_contract_keys():
-    """profiles/r01/bench_n1.json is the line bench.py printed on the MI355X: the driver's contract keys, the
+    """profiles/r0N/bench_n1.json are the lines bench.py printed on the MI355X: the driver's contract keys, the
     roofline object and the CPU baseline must all be there, and the numbers must be self-consistent."""
+    for tag in ("r01", "r02"):
+        _check_bench_line(os.path.join(ROOT, "profiles", tag, "bench_n1.json"))
     import json
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r01", "bench_n1.json")).read())
+    r02 = json.loads(open(os.path.join(ROOT, "profiles", "r02", "bench_n1.json")).read())
+    side = r02["also_measured"]["1m"]            # the north-star size on one GPU rides along
+    assert side["N"] == 1048576 and side["scaling"] == "strong"
+    assert abs(side["value"] - side["N"] ** 2 / (side["ms_per_step"] * 1e-3)) < 1e-6 * side["value"]
+
+
+def _check_bench_line(path):
+    import json
+    line = json.loads(open(path).read())
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k
