@@ -108,3 +108,46 @@ def test_analysis_scale_wide_latent_needs_no_pair_matrix():
                                     reduce_mean=False)
     with pytest.raises(N.LvaeError, match="training batches"):
         lqpm.sum().backward()
+
+
+@pytest.mark.parametrize("M,N,D", [(1, 1, 1), (5, 1, 3), (1, 7, 16), (33, 31, 17), (129, 257, 65)])
+def test_matrix_core_backward_ragged_and_tiny_shapes(M, N, D, monkeypatch):
+    monkeypatch.setenv("LVAE_BWD_PATH", "mfma")
+    mu, lv, z, a = _problem(100 + M + N + D, M, N, D)
+    _check(_our_grads(mu, lv, z, a), _reference_grads(mu, lv, z, a, math.log(N)), tol=2e-5)
+
+
+def test_matrix_core_backward_partial_outputs_through_the_c_abi(monkeypatch):
+    """Each output gradient on its own (NULL for the others) equals its entry of the full call: sweep B is skipped
+    without d_mu / d_logvar, sweep A always runs (it also yields the weight sums of the renormalisation)."""
+    from lvae import _native as N
+    from lvae import estimators as E
+    monkeypatch.setenv("LVAE_BWD_PATH", "mfma")
+    M, Nn, D = 700, 900, 40
+    mu, lv, z, a = _problem(77, M, Nn, D)
+    lq, _ = E.log_qz_raw(mu, lv, z, math.log(Nn), False)
+    nbytes = N._i64(0)
+    N.check(N.lib().lvae_log_qz_bwd_workspace_bytes(M, Nn, D, 0, nbytes))
+    ws = N.workspace(nbytes.value, z.device)
+
+    def call(want_z, want_mu, want_lv):
+        out = [torch.full_like(z, float("nan")) if want_z else None, torch.full_like(mu, float("nan")) if want_mu else None,
+               torch.full_like(lv, float("nan")) if want_lv else None]
+        N.check(N.lib().lvae_log_qz_bwd_f32(N.ptr(z), N.ptr(mu), N.ptr(lv), M, Nn, D, math.log(Nn), N.ptr(lq), N.ptr(a),
+                                            None, N.ptr(out[0]), N.ptr(out[1]), N.ptr(out[2]), N.ptr(ws), nbytes.value,
+                                            N.stream_ptr(z.device)))
+        return out
+
+    full = call(True, True, True)
+    assert all(bool(torch.isfinite(t).all()) for t in full)
+    for k in range(3):
+        want = [False, False, False]
+        want[k] = True
+        part = call(*want)
+        # (not bit for bit: the centring shift comes from float64 atomics whose order varies from call to call)
+        assert float((part[k] - full[k]).abs().max()) <= 1e-5 * float(full[k].abs().max())
+    # a workspace one byte short is refused before anything is launched
+    with pytest.raises(N.LvaeError, match="workspace"):
+        N.check(N.lib().lvae_log_qz_bwd_f32(N.ptr(z), N.ptr(mu), N.ptr(lv), M, Nn, D, math.log(Nn), N.ptr(lq), N.ptr(a),
+                                            None, N.ptr(full[0]), None, None, N.ptr(ws), nbytes.value - 1,
+                                            N.stream_ptr(z.device)))
