@@ -7,6 +7,9 @@
 
 // ---- launchers implemented in the kernel files --------------------------------------------------
 int lvae_launch_colsum(const float* mu, int64_t n, int D, PairHeader* hdr, hipStream_t st, double* zero5 = nullptr);
+bool lvae_colsum_single_ok(int64_t n, int D);
+int lvae_launch_colsum_single(const float* mu, int64_t n, int D, PairHeader* hdr, size_t clear_bytes, hipStream_t st,
+                              double* zero5 = nullptr);
 int lvae_launch_prep(int src, bool frag, const float* x, const float* spread, int spread_kind,
                      int64_t n, int64_t npad, int D, int DP, PairHeader* hdr, int64_t ngauss,
                      float* out, float* bias, float* dparams, int DC, hipStream_t st);
@@ -252,6 +255,16 @@ static int check_ws(const void* ws, int64_t ws_bytes, size_t need) {
     return LVAE_OK;
 }
 
+// Clears the header region (clear_bytes from hdr on) and accumulates the column sums of mu into it: one launch for
+// small inputs, a fill + the multi-workgroup kernel otherwise.
+static int clear_and_colsum(const float* mu, int64_t N, int D, PairHeader* hdr, size_t clear_bytes, hipStream_t st,
+                            double* zero5 = nullptr) {
+    if (lvae_colsum_single_ok(N, D) && clear_bytes <= 65536)
+        return lvae_launch_colsum_single(mu, N, D, hdr, (clear_bytes + 3) & ~(size_t)3, st, zero5);
+    LVAE_HIP(hipMemsetAsync(hdr, 0, clear_bytes, st));
+    return lvae_launch_colsum(mu, N, D, hdr, st, zero5);
+}
+
 static int check_pair_shapes(const float* z, const float* mu, const float* spread, int spread_kind,
                              int64_t M, int64_t N, int D) {
     LVAE_CHECK_ARG(z && mu && spread, "z, mu and spread must be non-NULL");
@@ -337,8 +350,7 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
         const bool gated_s = joint_path == LVAE_PATH_AUTO;
         const float limit_s = gated_s ? LVAE_COND_LIMIT : -1.0f;
         const bool djoint = joint_path != LVAE_PATH_MFMA;
-        LVAE_HIP(hipMemsetAsync(hdr, 0, sizeof(PairHeader), st));
-        rc = lvae_launch_colsum(mu, N, D, hdr, st, tail ? tail->sums : nullptr);
+        rc = clear_and_colsum(mu, N, D, hdr, sizeof(PairHeader), st, tail ? tail->sums : nullptr);
         if (rc) return rc;
         rc = lvae_launch_prep_pair(mu, spread, spread_kind, N, p.nblk * 32, z, M, p.cpad, D, p.DP, hdr, rfrag, rbias,
                                    need_direct ? dparams : nullptr, p.DC, cop, gated_s ? LVAE_COND_LIMIT : INFINITY, st);
@@ -374,10 +386,10 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     const bool auto_gate = want_joint && joint_path == LVAE_PATH_AUTO;
     const bool dparams_now = with_pm || (want_joint && joint_path == LVAE_PATH_DIRECT);
     // (the redo flags of the fixed-reference pass sit right behind the header: one fill for both)
-    LVAE_HIP(hipMemsetAsync(hdr, 0, need_mfma ? p.off_redo - p.off_hdr + (size_t)(p.cpad / 128 + 1) * sizeof(int)
-                                              : sizeof(PairHeader), st));
+    const size_t clear_bytes = need_mfma ? p.off_redo - p.off_hdr + (size_t)(p.cpad / 128 + 1) * sizeof(int)
+                                         : sizeof(PairHeader);
     if (p.DP) {
-        rc = lvae_launch_colsum(mu, N, D, hdr, st);
+        rc = clear_and_colsum(mu, N, D, hdr, clear_bytes, st);
         if (rc) return rc;
         rc = lvae_launch_prep(0, true, mu, spread, spread_kind, N, p.nblk * 32, D, p.DP, hdr, N,
                               bx ? nullptr : rfrag, rbias, dparams_now ? dparams : nullptr, p.DC, st);
@@ -400,6 +412,7 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
             if (rc) return rc;
         }
     } else {
+        LVAE_HIP(hipMemsetAsync(hdr, 0, clear_bytes, st));
         rc = lvae_launch_prep_dparams(mu, spread, spread_kind, N, D, p.DC, dparams, nullptr, 0.f, st);
         if (rc) return rc;
     }
@@ -677,8 +690,7 @@ extern "C" int lvae_log_qz_bwd_f32(const float* z, const float* mu, const float*
     PairHeader* hdr = (PairHeader*)(base + p.off_hdr);
     const PairHeader* gate = nullptr;        // non-NULL: the vector-ALU kernels run iff cond > LVAE_BWD_COND_LIMIT
     if (use_mfma) {
-        LVAE_HIP(hipMemsetAsync(hdr, 0, sizeof(PairHeader), st));
-        rc = lvae_launch_colsum(mu, N, D, hdr, st);
+        rc = clear_and_colsum(mu, N, D, hdr, sizeof(PairHeader), st);
         if (rc) return rc;
         rc = lvae_launch_bwd_mfma(g.mf, base + g.off_mfma, z, mu, logvar, M, N, D, log_norm, log_qz, g_log_qz, hdr,
                                   use_valu ? LVAE_BWD_COND_LIMIT : -1.0f, d_z, d_mu, d_logvar, st);
@@ -795,8 +807,7 @@ extern "C" int lvae_qz_estimate_f32(const float* z, const float* mu, const float
     float* cop = (float*)(base + p.off_cop);
     float* colbias = (float*)(base + p.off_colbias);
     float2* partial = (float2*)(base + p.off_partial);
-    LVAE_HIP(hipMemsetAsync(hdr, 0, sizeof(PairHeader), st));
-    rc = lvae_launch_colsum(mu, N, D, hdr, st);
+    rc = clear_and_colsum(mu, N, D, hdr, sizeof(PairHeader), st);
     if (rc) return rc;
     rc = lvae_launch_prep(1, true, z, nullptr, 0, M, p.nblk * 32, D, p.DP, hdr, N, rfrag, rbias,
                           nullptr, p.DC, st);

@@ -473,6 +473,62 @@ finalize_pm_sum_kernel(const float* __restrict__ tmp, int64_t cpad, int64_t C, i
     out[i] = (float)total;
 }
 
+// Small inputs (n * D <= COLSUM_SINGLE_MAX, D a multiple of 4 dividing 4096): ONE workgroup clears the header and writes
+// the column sums itself -- no hipMemsetAsync ahead of it (a fill packet followed by a dependent kernel costs an
+// 11 us gap on the queue) and no atomics.
+#define COLSUM_SINGLE_MAX 262144
+__global__ void __launch_bounds__(1024)
+colsum_single_kernel(const float* __restrict__ mu, int64_t n, int D, PairHeader* hdr, size_t clear_bytes,
+                     double* __restrict__ zero5) {
+    __shared__ float sm4[4096];
+    __shared__ double sm_d[128 * 8];
+    const int tid = threadIdx.x;
+    unsigned* w = reinterpret_cast<unsigned*>(hdr);
+    for (size_t i = tid; i < clear_bytes / 4; i += 1024) w[i] = 0u;
+    if (zero5 && tid < 5) zero5[tid] = 0.0;
+    const f32x4* __restrict__ m4 = reinterpret_cast<const f32x4*>(mu);
+    const int64_t q1 = n * D / 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int64_t i = tid;
+    for (; i + 3072 < q1; i += 4096) {
+        const f32x4 a = m4[i], b = m4[i + 1024], c = m4[i + 2048], d = m4[i + 3072];
+        acc += (a + b) + (c + d);
+    }
+    for (; i < q1; i += 1024) acc += m4[i];
+    *reinterpret_cast<f32x4*>(sm4 + 4 * tid) = acc;
+    __syncthreads();               // (also orders the clearing stores above before the sums below)
+    // column d is held by the floats d, d + D, d + 2D, ...: eight threads per column, then one adds the eight
+    const int per = 4096 / D;
+    if (tid < D * 8) {
+        const int d = tid >> 3, part = tid & 7;
+        double t = 0.0;
+        for (int k = part; k < per; k += 8) t += (double)sm4[d + k * D];
+        sm_d[tid] = t;
+    }
+    __syncthreads();
+    if (tid < D) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sm_d[tid * 8 + k];
+        hdr->colsum[tid] = t;
+    }
+}
+
+bool lvae_colsum_single_ok(int64_t n, int D) {
+    return D >= 4 && D <= 128 && (D & 3) == 0 && 4096 % D == 0 && n * D <= COLSUM_SINGLE_MAX;
+}
+
+// Clears `clear_bytes` of the workspace from the header on (a multiple of 4, at least sizeof(PairHeader)) and
+// accumulates the column sums, in one launch.  Only when lvae_colsum_single_ok.
+int lvae_launch_colsum_single(const float* mu, int64_t n, int D, PairHeader* hdr, size_t clear_bytes, hipStream_t st,
+                              double* zero5) {
+    if (!lvae_colsum_single_ok(n, D) || clear_bytes < sizeof(PairHeader) || (clear_bytes & 3))
+        return lvae_set_error(LVAE_ERR_INVALID, "colsum_single: unsupported shape");
+    hipLaunchKernelGGL(colsum_single_kernel, dim3(1), dim3(1024), 0, st, mu, n, D, hdr, clear_bytes, zero5);
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
 // ---- host launchers ----------------------------------------------------------------------------
 int lvae_launch_colsum(const float* mu, int64_t n, int D, PairHeader* hdr, hipStream_t st, double* zero5) {
     if (D > 128) return lvae_set_error(LVAE_ERR_INVALID, "colsum: D > 128");
