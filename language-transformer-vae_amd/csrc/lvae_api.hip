@@ -294,10 +294,11 @@ struct StatsTail {
     double* sums;
 };
 
-// Largest N * M served by the small path (five launches, running-maximum epilogue in one pass: its lower MFMA
-// rate costs less than the shift / redo / second-merge launches of the fixed-reference form up to ~5,800^2), and
-// the most samples its one-workgroup merge handles.
-#define LVAE_SMALL_PAIRS 33554432.0
+// Largest N * M served by the small path (five launches, running-maximum epilogue in one pass: its lower MFMA rate
+// costs less than the shift / redo / second-merge launches of the fixed-reference form up to ~12,600^2 -- measured,
+// tools/sweep_small_threshold.py, D = 32: 48 vs 76 us at 4,096^2, 109 vs 127 at 8,192^2, 213 vs 229 at 12,288^2,
+// 326 vs 322 at 16,384^2), and the most samples its merge handles.
+#define LVAE_SMALL_PAIRS 160000000.0
 #define LVAE_SMALL_MAX_M 16384
 
 // Shared driver: samples on the kept axis, posteriors on the reduced axis.
@@ -344,7 +345,9 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     // ---- small problems: memset, column sums, ONE operand-prep launch, the pair kernel(s) with the running-maximum
     //      epilogue, ONE merge (+ statistics) launch.  Same kernels, same device-side conditioning gate.
     const double pairs = (double)N * (double)M;
-    const bool small = p.DP != 0 && !bx && want_joint && pairs <= LVAE_SMALL_PAIRS && M <= LVAE_SMALL_MAX_M &&
+    const char* sp_env = getenv("LVAE_SMALL_PAIRS");      // (threshold sweeps: tools/sweep_small_threshold.py)
+    const double small_pairs = sp_env ? atof(sp_env) : LVAE_SMALL_PAIRS;
+    const bool small = p.DP != 0 && !bx && want_joint && pairs <= small_pairs && M <= LVAE_SMALL_MAX_M &&
                        !(with_pm && pairs >= LVAE_PM_BX_MIN_PAIRS) && !getenv("LVAE_NO_SMALL_PATH");
     if (small) {
         const bool gated_s = joint_path == LVAE_PATH_AUTO;
