@@ -55,7 +55,8 @@ int lvae_launch_iw_lse(const float* a, const float* b, const float* c, int64_t B
                        hipStream_t st);
 
 int lvae_launch_latent_sums(const float* z, const float* mu, const float* logvar, const float* log_qz,
-                            const float* log_qz_pm, int64_t M, int D, double* sums, hipStream_t st);
+                            const float* log_qz_pm, int64_t M, int D, double* sums, hipStream_t st,
+                            bool sums_are_zero = false);
 
 int lvae_launch_pair_mfma(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                           float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
@@ -392,7 +393,7 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     const size_t clear_bytes = need_mfma ? p.off_redo - p.off_hdr + (size_t)(p.cpad / 128 + 1) * sizeof(int)
                                          : sizeof(PairHeader);
     if (p.DP) {
-        rc = clear_and_colsum(mu, N, D, hdr, clear_bytes, st);
+        rc = clear_and_colsum(mu, N, D, hdr, clear_bytes, st, tail ? tail->sums : nullptr);   // (also zeroes the statistics)
         if (rc) return rc;
         rc = lvae_launch_prep(0, true, mu, spread, spread_kind, N, p.nblk * 32, D, p.DP, hdr, N,
                               bx ? nullptr : rfrag, rbias, dparams_now ? dparams : nullptr, p.DC, st);
@@ -487,7 +488,7 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
                                      (float*)(base + p.off_pmtmp), log_qz_pm, st);
         if (rc) return rc;
     }
-    if (tail) return lvae_launch_latent_sums(z, tail->mu, tail->logvar, log_qz, log_qz_pm, M, D, tail->sums, st);
+    if (tail) return lvae_launch_latent_sums(z, tail->mu, tail->logvar, log_qz, log_qz_pm, M, D, tail->sums, st, p.DP != 0);
     return LVAE_OK;
 }
 

@@ -257,8 +257,8 @@ __global__ void __launch_bounds__(1024)
 prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ spread, int spread_kind,
                     int64_t n, int64_t npad, int D, int DP, PairHeader* hdr, double inv_ngauss,
                     float* __restrict__ out, float* __restrict__ bias, float* __restrict__ dparams,
-                    int DC) {
-    prep_rows<SRC, FRAG>(blockIdx.x, PREP_RB, x, spread, spread_kind, n, npad, D, DP, hdr, inv_ngauss, out, bias,
+                    int DC, int rb) {
+    prep_rows<SRC, FRAG>(blockIdx.x, rb, x, spread, spread_kind, n, npad, D, DP, hdr, inv_ngauss, out, bias,
                          dparams, DC);
 }
 
@@ -542,11 +542,13 @@ int lvae_launch_prep(int src, bool frag, const float* x, const float* spread, in
                      int64_t n, int64_t npad, int D, int DP, PairHeader* hdr, int64_t ngauss,
                      float* out, float* bias, float* dparams, int DC, hipStream_t st) {
     const int threads = 32 * (DP / 4);
-    const dim3 grid((unsigned)lvae_ceil_div(npad, 32 * PREP_RB));
+    int rb = PREP_RB;
+    if (getenv("LVAE_PREP_RB")) rb = atoi(getenv("LVAE_PREP_RB")) > 0 ? atoi(getenv("LVAE_PREP_RB")) : rb;   // (sweeps)
+    const dim3 grid((unsigned)lvae_ceil_div(npad, 32 * rb));
     const double inv = 1.0 / (double)ngauss;
 #define LVAE_PREP(S, F)                                                                          \
     hipLaunchKernelGGL((prep_operand_kernel<S, F>), grid, dim3(threads), 0, st, x, spread,        \
-                       spread_kind, n, npad, D, DP, hdr, inv, out, bias, dparams, DC)
+                       spread_kind, n, npad, D, DP, hdr, inv, out, bias, dparams, DC, rb)
     if (src == 3 && frag) LVAE_PREP(3, true);
     else if (src == 4 && !frag) LVAE_PREP(4, false);
     else if (src == 0 && frag) LVAE_PREP(0, true);

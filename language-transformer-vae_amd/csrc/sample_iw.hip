@@ -586,13 +586,15 @@ int lvae_launch_finalize_small(const float2* partial_a, int nsplit_a, const floa
 }
 
 int lvae_launch_latent_sums(const float* z, const float* mu, const float* logvar, const float* log_qz,
-                            const float* log_qz_pm, int64_t M, int D, double* sums, hipStream_t st) {
+                            const float* log_qz_pm, int64_t M, int D, double* sums, hipStream_t st,
+                            bool sums_are_zero) {
     int G = 0;
     if (!vec_ok(D, &G)) G = 0;
     const int64_t rows_per_block = G ? 256 / G : 256;
     int64_t blocks = lvae_ceil_div(M, rows_per_block);
-    if (blocks > 512) blocks = 512;      // four float64 atomics per block land on the same four words
-    LVAE_HIP(hipMemsetAsync(sums, 0, 5 * sizeof(double), st));
+    if (blocks > 1024) blocks = 1024;    // four float64 atomics per block land on the same four words
+    // (sums_are_zero: an earlier kernel of the same call cleared them -- no fill packet ahead of this launch)
+    if (!sums_are_zero) LVAE_HIP(hipMemsetAsync(sums, 0, 5 * sizeof(double), st));
     hipLaunchKernelGGL(latent_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, st, z, mu, logvar, log_qz,
                        log_qz_pm, M, D, G, sums);
     LVAE_LAUNCH_CHECK();
