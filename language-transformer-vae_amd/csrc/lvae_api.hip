@@ -655,7 +655,13 @@ extern "C" int lvae_log_qz_bwd_workspace_bytes(int64_t M, int64_t N, int D, int 
                                                int64_t* out_bytes) {
     LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
     LVAE_CHECK_ARG(M >= 1 && N >= 1 && D >= 1, "need M, N, D >= 1");
-    *out_bytes = (int64_t)grad_layout(M, N, D, prod_marginals != 0).total;
+    // (a workspace sized for the prod-marginals gradient also serves a call that passes g_log_qz alone)
+    size_t need = grad_layout(M, N, D, false).total;
+    if (prod_marginals) {
+        const size_t with_pm = grad_layout(M, N, D, true).total;
+        if (with_pm > need) need = with_pm;
+    }
+    *out_bytes = (int64_t)need;
     return LVAE_OK;
 }
 

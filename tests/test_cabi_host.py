@@ -211,3 +211,15 @@ def test_mmd_workspace_queries_cover_the_layout_of_every_mode():
             for which in (0, 1, 2):
                 N.check(lib.lvae_layout_info(2, na, nb, D, which, info))
                 assert info[0] <= out.value, ("mmd_rbf", na, nb, D, which)
+
+
+def test_backward_workspace_query_covers_both_gradient_modes():
+    """lvae_log_qz_bwd_f32 picks its path from the gradients it is given; a workspace sized with prod_marginals = 1
+    must also serve the call that passes g_log_qz alone (the matrix-core sweeps' region)."""
+    from lvae import _native as N
+    lib = N.lib()
+    for M, Nn, D in ((32, 32, 32), (300, 7, 5), (4096, 4096, 64), (20000, 20000, 96), (16384, 16384, 128), (100, 100, 200)):
+        a, b = N._i64(0), N._i64(0)
+        N.check(lib.lvae_log_qz_bwd_workspace_bytes(M, Nn, D, 0, a))
+        N.check(lib.lvae_log_qz_bwd_workspace_bytes(M, Nn, D, 1, b))
+        assert b.value >= a.value > 0, (M, Nn, D)
