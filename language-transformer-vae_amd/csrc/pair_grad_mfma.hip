@@ -123,12 +123,12 @@ bwd_prep_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, 
         }
         return h == 0 ? v : v * v;
     };
-    for (int idx = tid; idx < 64 * DP; idx += 256) {       // A operand of the density contraction: [s/4][row][h][s%4]
-        const int e = idx & 3, h = (idx >> 2) & 1, row = (idx >> 3) & 31, sg = idx >> 8;
+    for (int idx = tid; idx < 64 * DP; idx += 256) {       // A operand of the density contraction: [s/4][h][row][s%4] (16 B per lane, lane = row + 32 h)
+        const int e = idx & 3, row = (idx >> 2) & 31, h = (idx >> 7) & 1, sg = idx >> 8;     // slot = lane = row + 32 h
         rec[idx] = dens(row, h, 4 * sg + e);
     }
-    for (int idx = tid; idx < 64 * DP; idx += 256) {       // A operand of the feature contraction: [f/32][q][f%32][h][e]
-        const int e = idx & 3, h = (idx >> 2) & 1, fl = (idx >> 3) & 31, q = (idx >> 8) & 3, ft = idx >> 10;
+    for (int idx = tid; idx < 64 * DP; idx += 256) {       // A operand of the feature contraction: [f/32][q][h][f%32][e]
+        const int e = idx & 3, fl = (idx >> 2) & 31, h = (idx >> 7) & 1, q = (idx >> 8) & 3, ft = idx >> 10;
         const int f = ft * 32 + fl, row = 8 * q + 4 * h + e;
         const int half = f >= DP, d = f - half * DP;
         const float v = p0[row * LD + d];
@@ -241,7 +241,7 @@ pair_bwd_mfma_kernel(const float* __restrict__ rec, const float* __restrict__ co
             }
 #pragma unroll
             for (int sg = 2 * gi; sg < 2 * gi + 2; ++sg) {
-                const f32x4 a4 = *reinterpret_cast<const f32x4*>(st + ((sg * 32 + r) * 2 + h) * 4);
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(st + (sg * 64 + lane) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], bc[4 * sg + e], acc, 0, 0, 0);
             }
@@ -270,7 +270,7 @@ pair_bwd_mfma_kernel(const float* __restrict__ rec, const float* __restrict__ co
             f32x4 f4[NFT];
 #pragma unroll
             for (int t = 0; t < NFT; ++t)
-                f4[t] = *reinterpret_cast<const f32x4*>(st + 64 * DP + (((t * 4 + q) * 32 + r) * 2 + h) * 4);
+                f4[t] = *reinterpret_cast<const f32x4*>(st + 64 * DP + ((t * 4 + q) * 64 + lane) * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
