@@ -12,8 +12,34 @@
 // Algorithmic bytes per (sentence, sample): 4*D (eps) + 4 (log_p_x_z) read, + 4*D when z is written.
 #include "pair_plan.h"
 
+// Partner value for a SUM over 2*O adjacent lanes, without the LDS crossbar where the data-parallel-primitive
+// modifiers reach: O = 1, 2 quad permutations (lane ^ 1, lane ^ 2), O = 4 the half-row mirror (lane 7 - i of every
+// eight: not lane ^ 4, but it also pairs the lower four lanes with the upper four one to one, which is all a
+// sum -- or a reduce-scatter keyed on bit 2 -- needs), O = 8 a rotation by eight inside the 16-lane row
+// (= lane ^ 8).  Wider distances go through ds_bpermute.  All lanes of the wave must be active.
+template <int O>
+__device__ __forceinline__ float sum_partner(float v) {
+    if constexpr (O == 1 || O == 2 || O == 4 || O == 8) {
+        constexpr int ctrl = O == 1 ? 0xB1 : (O == 2 ? 0x4E : (O == 4 ? 0x141 : 0x128));
+        const int x = __float_as_int(v);
+        return __int_as_float(__builtin_amdgcn_mov_dpp(x, ctrl, 0xF, 0xF, true));
+    } else {
+        return __shfl_xor(v, O, 64);
+    }
+}
+
+template <int O>
+__device__ __forceinline__ void group_sum_level(float& v, int G) {
+    if (O < G) v += sum_partner<O>(v);
+}
+
 __device__ __forceinline__ float group_sum(float v, int G) {
-    for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    group_sum_level<32>(v, G);
+    group_sum_level<16>(v, G);
+    group_sum_level<8>(v, G);
+    group_sum_level<4>(v, G);
+    group_sum_level<2>(v, G);
+    group_sum_level<1>(v, G);
     return v;
 }
 
@@ -34,22 +60,41 @@ __device__ __forceinline__ void lse_push(float& m, float& s, float w) {
 // Sum of U per-row partials over the G lanes of a row group, leaving row (gl % U) in lane gl: levels wider than U
 // are plain butterflies, the last log2(U) levels a reduce-scatter (each level halves what a lane still carries):
 // G = U = 8 takes 7 shuffles per quantity instead of 24.
+template <int U, int O>
+__device__ __forceinline__ void scatter_level(float (&a)[U], int gl) {      // a lane keeps the half of its rows that bit O selects
+    if constexpr (O >= 1) {
+        const bool up = (gl & O) != 0;
+#pragma unroll
+        for (int u = 0; u < O; ++u) {
+            const float send = up ? a[u] : a[u + O];
+            const float keep = up ? a[u + O] : a[u];
+            a[u] = keep + sum_partner<O>(send);
+        }
+        scatter_level<U, O / 2>(a, gl);
+    }
+}
+
 template <int U>
 __device__ __forceinline__ float reduce_rows(float (&a)[U], int gl, int G) {
-    for (int o = G >> 1; o >= U; o >>= 1) {
+    for (int o = G >> 1; o >= U; o >>= 1) {       // plain butterflies: every lane keeps all U rows
+        if (o == 8) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) a[u] += __shfl_xor(a[u], o, 64);
-    }
+            for (int u = 0; u < U; ++u) a[u] += sum_partner<8>(a[u]);
+        } else if (o == 4) {
 #pragma unroll
-    for (int o = U >> 1; o >= 1; o >>= 1) {
-        const bool up = (gl & o) != 0;
+            for (int u = 0; u < U; ++u) a[u] += sum_partner<4>(a[u]);
+        } else if (o == 2) {
 #pragma unroll
-        for (int u = 0; u < o; ++u) {
-            const float send = up ? a[u] : a[u + o];
-            const float keep = up ? a[u + o] : a[u];
-            a[u] = keep + __shfl_xor(send, o, 64);
+            for (int u = 0; u < U; ++u) a[u] += sum_partner<2>(a[u]);
+        } else if (o == 1) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) a[u] += sum_partner<1>(a[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) a[u] += __shfl_xor(a[u], o, 64);
         }
     }
+    scatter_level<U, U / 2>(a, gl);
     return a[0];
 }
 
@@ -65,7 +110,11 @@ __global__ void __launch_bounds__(TPB)
 sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
                  const float* __restrict__ src, const float* __restrict__ log_p_x_z, int64_t K, int D,
                  int G, float* __restrict__ z_out, float* __restrict__ log_q_z_x,
-                 float* __restrict__ log_p_z, float* __restrict__ iw_ll) {
+                 float* __restrict__ log_p_z, float* __restrict__ iw_ll, int stage) {
+    // stage != 0 (K a multiple of 4, 2*K floats of dynamic LDS): the sentence's two [K] output rows are collected in
+    // LDS and leave as full 16-byte-per-lane stores at the end, instead of one 128-byte piece per wave and pass
+    // (131 MB of such pieces cost the C5 stream 0.06 ms: 0.39 -> 0.33 ms without them)
+    extern __shared__ __attribute__((aligned(16))) float iw_stage[];
     const int64_t b = blockIdx.x;
     const int gl = threadIdx.x % G;          // lane inside the row group: owns dims 4*gl .. 4*gl+3
     const int rows_per_iter = (TPB / G) * U;
@@ -138,12 +187,18 @@ sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
                 __builtin_nontemporal_store(zz4, reinterpret_cast<f32x4*>(z_out + (b * K + kw + u * Gw) * D + 4 * gl));
             aq[u] = cq - (q2[0] + q2[1]);
             ap[u] = cp - 0.5f * (p2[0] + p2[1]);
+            __builtin_amdgcn_sched_barrier(0);      // one row at a time: interleaved rows only lengthen live ranges
         }
         const float my_lq = have_post ? reduce_rows<U>(aq, gl, G) : 0.f;
         const float my_lp = reduce_rows<U>(ap, gl, G);
         if (mine) {
-            if (log_q_z_x) log_q_z_x[b * K + kmine] = my_lq;
-            if (log_p_z) log_p_z[b * K + kmine] = my_lp;
+            if (stage) {
+                if (log_q_z_x) iw_stage[kmine] = my_lq;
+                if (log_p_z) iw_stage[K + kmine] = my_lp;
+            } else {
+                if (log_q_z_x) log_q_z_x[b * K + kmine] = my_lq;
+                if (log_p_z) log_p_z[b * K + kmine] = my_lp;
+            }
             if (iw_ll) lse_push(lm, ls, pxz + my_lp - my_lq);
         }
     };
@@ -151,14 +206,27 @@ sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
         for (int64_t k0 = 0; k0 < K; k0 += 2 * rows_per_iter) {
             const bool second = k0 + rows_per_iter < K;
             if (second) issue(vb, kw0 + k0 + rows_per_iter);
-            consume(va, kw0 + k0);
+            __builtin_amdgcn_sched_barrier(0);      // (keeps the two passes' arithmetic apart: interleaved, their
+            consume(va, kw0 + k0);                  //  live ranges cost 40 registers and two waves per SIMD)
+            __builtin_amdgcn_sched_barrier(0);
             if (k0 + 2 * rows_per_iter < K) issue(va, kw0 + k0 + 2 * rows_per_iter);
+            __builtin_amdgcn_sched_barrier(0);
             if (second) consume(vb, kw0 + k0 + rows_per_iter);
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {
         for (int64_t k0 = 0; k0 < K; k0 += rows_per_iter) {
             if (k0) issue(va, kw0 + k0);
             consume(va, kw0 + k0);
+        }
+    }
+    if (stage) {
+        __syncthreads();
+        const f32x4* sq = reinterpret_cast<const f32x4*>(iw_stage);
+        const f32x4* sp = reinterpret_cast<const f32x4*>(iw_stage + K);
+        for (int i = threadIdx.x; i < (int)(K >> 2); i += TPB) {
+            if (log_q_z_x) reinterpret_cast<f32x4*>(log_q_z_x + b * K)[i] = sq[i];
+            if (log_p_z) reinterpret_cast<f32x4*>(log_p_z + b * K)[i] = sp[i];
         }
     }
     if (iw_ll) {
@@ -332,8 +400,9 @@ int lvae_launch_sample_iw(bool from_eps, const float* mu, const float* logvar, c
         // 256 only lose (measured at C5: 0.46 / 0.52 / 0.63 ms at 256 / 512 / 1024 threads)
         // U = loads in flight per lane in one pass, software-pipelined over two register buffers.  Measured at C5
         // (tools/bench_iw_variants.py; LVAE_IW_PIPE / LVAE_IW_U override for such sweeps): when z is written, U = 8
-        // (0.77 ms, 5.7 TB/s; U = 4: 0.80); the read-only reduction prefers U = 4 -- fewer registers, more waves,
-        // 16 KB passes -- at 0.41 ms = 5.6 TB/s (U = 8: 0.47; the un-pipelined U = 8 kernel of round 1: 0.44).
+        // (0.78 ms, 5.6 TB/s; U = 4: 0.81); the read-only reduction prefers U = 4 -- fewer registers, more waves,
+        // 16 KB passes -- at 0.405-0.41 ms = 5.6 TB/s (U = 2: 0.43; the un-pipelined U = 8 kernel of round 1: 0.44).
+        // (tools/sweep_iw.py, after the row reduction moved from ds_bpermute to data-parallel-primitive adds)
         int umax = G < 8 ? G : 8;
         if (!(from_eps && z_out) && umax > 4) umax = 4;
         bool pipe = true;
@@ -342,9 +411,15 @@ int lvae_launch_sample_iw(bool from_eps, const float* mu, const float* logvar, c
         const int tpb = K <= (64 / G) * umax ? 64 : (K <= (128 / G) * umax ? 128 : 256);
         if (K <= (int64_t)(tpb / G) * umax * 2 && !getenv("LVAE_IW_PIPE")) pipe = false;     // one or two passes: the
                                                           // single-buffer form needs fewer registers (more waves)
+        // [B,K] outputs through LDS (see the kernel): K a multiple of 4 from 256 (K = 100 measured 2 % slower) up to 2,048
+        // (16 KB), 16-byte aligned rows; LVAE_IW_NO_STAGE=1 for comparisons
+        const bool al16 = (((uintptr_t)log_q_z_x | (uintptr_t)log_p_z) & 15) == 0;
+        const int stage = ((log_q_z_x || log_p_z) && K % 4 == 0 && K >= 256 && K <= 2048 && al16 &&
+                           !getenv("LVAE_IW_NO_STAGE")) ? 1 : 0;
+        const size_t dyn = stage ? (size_t)2 * K * sizeof(float) : 0;
 #define LVAE_SIW2(E, UU, T, P)                                                                             \
-    hipLaunchKernelGGL((sample_iw_kernel<E, UU, T, P>), grid, dim3(T), 0, st, mu, logvar, src, log_p_x_z, K, D, G, \
-                       z_out, log_q_z_x, log_p_z, iw_ll)
+    hipLaunchKernelGGL((sample_iw_kernel<E, UU, T, P>), grid, dim3(T), dyn, st, mu, logvar, src, log_p_x_z, K, D, G, \
+                       z_out, log_q_z_x, log_p_z, iw_ll, stage)
 #define LVAE_SIW(E, UU)                                                                             \
     do {                                                                                            \
         if (tpb == 64) { if (pipe) LVAE_SIW2(E, UU, 64, true); else LVAE_SIW2(E, UU, 64, false); }        \

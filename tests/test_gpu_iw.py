@@ -78,6 +78,32 @@ def test_reparam_iw_vs_c_oracle_large():
     np.testing.assert_allclose(out1["iw_ll"].cpu().numpy(), w, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("D", [4, 8, 16, 32, 64, 128, 256, 20])
+def test_reparam_iw_row_geometries(D):
+    """Every lane-group width of the row reduction (G = D/4 = 1 ... 64 lanes: quad permutations, half-row mirror,
+    row rotation, cross-row shuffles; D = 20 takes the generic kernel) and both output routes -- [B,K] rows staged
+    through LDS (K a multiple of 4 from 256) and written piecewise (other K) -- against the C oracle."""
+    from lvae import estimators as E
+    from oracle import oracle_c
+    rng = np.random.default_rng(D)
+    for B, K in ((5, 256), (3, 1000), (4, 259), (7, 100), (2, 2052), (9, 7)):
+        mu = rng.standard_normal((B, D)).astype(np.float32)
+        lv = (0.5 * rng.standard_normal((B, D)) - 1).astype(np.float32)
+        eps = rng.standard_normal((B, K, D)).astype(np.float32)
+        lpxz = (5 * rng.standard_normal((B, K)) - 100).astype(np.float32)
+        z, lq, lp, iw = oracle_c.reparam_iw(mu, lv, eps, lpxz)
+        for return_z in (False, True):
+            out = E.reparam_iw(dev(mu), dev(lv), dev(eps), dev(lpxz), return_z=return_z)
+            if return_z:
+                np.testing.assert_allclose(out["latent_z"].cpu().numpy(), z, rtol=1e-6, atol=1e-6)
+            np.testing.assert_allclose(out["log_q_z_x"].cpu().numpy(), lq, rtol=1e-4, atol=1e-3, err_msg=f"K={K}")
+            np.testing.assert_allclose(out["log_p_z"].cpu().numpy(), lp, rtol=1e-4, atol=1e-3, err_msg=f"K={K}")
+            np.testing.assert_allclose(out["iw_ll"].cpu().numpy(), iw, rtol=1e-4, atol=1e-3, err_msg=f"K={K}")
+        # densities of given z (no reparameterisation): the same row reduction with z as the source
+        lq2 = E.sample_log_likelihood(dev(z), dev(mu), dev(lv), reduce_batch_dim=False)
+        np.testing.assert_allclose(lq2.cpu().numpy(), lq, rtol=1e-4, atol=1e-3)
+
+
 def test_iw_full_size_properties():
     """BASELINE configs[4] at full size (K = 1,000 samples x 16,384 sentences, D = 32), through properties:
     a constant added to log p(x|z) shifts the IW estimate by that constant, the estimate lies between the
