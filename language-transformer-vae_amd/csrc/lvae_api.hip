@@ -12,7 +12,8 @@ int lvae_launch_colsum_single(const float* mu, int64_t n, int D, PairHeader* hdr
                               double* zero5 = nullptr);
 int lvae_launch_prep(int src, bool frag, const float* x, const float* spread, int spread_kind,
                      int64_t n, int64_t npad, int D, int DP, PairHeader* hdr, int64_t ngauss,
-                     float* out, float* bias, float* dparams, int DC, hipStream_t st);
+                     float* out, float* bias, float* dparams, int DC, hipStream_t st,
+                     float cond_floor = -1.f);
 int lvae_launch_prep_dparams(const float* mu, const float* spread, int spread_kind, int64_t n, int D,
                              int DC, float* dparams, const PairHeader* gate_hdr, float cond_limit,
                              hipStream_t st);
@@ -395,8 +396,10 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     if (p.DP) {
         rc = clear_and_colsum(mu, N, D, hdr, clear_bytes, st, tail ? tail->sums : nullptr);   // (also zeroes the statistics)
         if (rc) return rc;
+        // (gated calls only compare the conditioning estimate with the limit: workgroups below it publish nothing)
         rc = lvae_launch_prep(0, true, mu, spread, spread_kind, N, p.nblk * 32, D, p.DP, hdr, N,
-                              bx ? nullptr : rfrag, rbias, dparams_now ? dparams : nullptr, p.DC, st);
+                              bx ? nullptr : rfrag, rbias, dparams_now ? dparams : nullptr, p.DC, st,
+                              auto_gate ? LVAE_COND_LIMIT : -1.f);
         if (rc) return rc;
         if (bx && need_mfma) {   // limb operands into the same regions (the fp32 prep above still owns bias + header)
             rc = lvae_launch_prep_bf16x3(0, true, mu, spread, spread_kind, N, p.nblk * 32, D, p.DP, hdr, N,
@@ -1517,7 +1520,8 @@ extern "C" int lvae_kernel_matrix_f32(const float* x, const float* y, int64_t n1
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     PairHeader* hdr = (PairHeader*)ws;
-    static_assert(sizeof(PairHeader) <= LVAE_KMAT_WS_BYTES, "header larger than the kernel-matrix workspace");
+    // (only the kernel-sum parameters are touched here; the normaliser slots at the end of the header belong to log q(z))
+    static_assert(offsetof(PairHeader, slot) <= LVAE_KMAT_WS_BYTES, "header larger than the kernel-matrix workspace");
     rc = lvae_launch_set_ksum(hdr, kp, st);
     if (rc) return rc;
     return lvae_launch_pair_matrix(x, nullptr, 0, y, n1, n2, D, 1, hdr, out, st);

@@ -22,17 +22,30 @@ struct KsumParams {
     float c[LVAE_KSUM_MAX + 1];
 };
 
+// Normaliser statistics of the posteriors, spread over LVAE_NORM_SLOTS cache lines: every workgroup of the operand
+// preparation adds its share to slot (workgroup index mod slots), lse_shift_bias_kernel folds the slots.  (All
+// workgroups on ONE line cost ~35 ns each, device-scope atomics on a single address serialise at the memory side:
+// 77 us for the 2,048 workgroups of C2 at one 32-row block each.)
+#define LVAE_NORM_SLOTS 64
+struct NormSlot {
+    unsigned int cmax_key;   // order-preserving key of the largest density normaliser max_j -0.5 log2 prod_d(2 pi var_jd)
+    unsigned int pad_;
+    double norm_sum;         // sum_j of the density normalisers (their mean locates the typical posterior)
+    unsigned int fill_[28];  // one slot = 128 bytes
+};
+
 // Lives at the start of the workspace; zeroed (hipMemsetAsync) at the start of every call.
 struct PairHeader {
     double colsum[128];      // per-dimension sum of the posterior means (centering shift * R_gauss)
     unsigned int cond_bits;  // float bits of max_j conditioning estimate (non-negative -> uint order)
-    unsigned int cmax_key;   // order-preserving key of the largest density normaliser max_j -0.5 log2 prod_d(2 pi var_jd)
+    unsigned int unused0_;
     float lse_ref;           // reference the row biases were shifted by: every term <= 2^LSE_HEADROOM
     unsigned int lse_skip;   // 1: the fixed-reference pass is pointless (see lse_shift_bias_kernel), go straight to the redo
-    double norm_sum;         // sum_j of the density normalisers (their mean locates the typical posterior)
+    double unused1_;
     unsigned int pad_[58];
     KsumParams ksum;         // kernel-matrix epilogue parameters (copied in by the MMD entry point)
     unsigned int pad2_[27];
+    NormSlot slot[LVAE_NORM_SLOTS];
 };
 
 // Arguments of the label-permutation mode of the MFMA pair kernel (MMD permutation test).

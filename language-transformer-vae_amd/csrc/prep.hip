@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ m
 // SRC 3 / 4 (kernel sums): linear-only operands with TWO dimensions per MFMA step (DP = padded D / 2): POINT
 // rows -2y (k-half 0: dimension 2s, k-half 1: dimension 2s + 1) with bias |y|^2 (+inf on padded rows), SAMPLE
 // rows x with `bias` receiving |x|^2 (the per-column norm the epilogue adds); no centering shift.
-#define PREP_RB 4
+#define PREP_RB 2      // (C2 posteriors, 65,536 x 32: 11.3 us at 1 or 2 blocks per workgroup, 12.8 at 4, 18 at 8)
 // (a device function so that one launch can prepare both operands of a small problem, prep_pair_kernel below:
 //  `wg` stands for blockIdx.x, `rb` for the 32-row blocks a workgroup covers)
 template <int SRC, bool FRAG>
@@ -244,8 +244,9 @@ prep_rows(const int64_t wg, const int rb, const float* __restrict__ x, const flo
                 //  workgroups' atomics on these three words were a third of the launch at 4,096 posteriors)
                 if (cond_max > cond_floor) atomicMax(&hdr->cond_bits, __float_as_uint(cond_max));
                 if (want_norm) {
-                    atomicMax(&hdr->cmax_key, lvae_float_key(norm_max));
-                    if (FRAG) atomicAdd(&hdr->norm_sum, (double)norm_acc);
+                    NormSlot* sl = &hdr->slot[wg & (LVAE_NORM_SLOTS - 1)];
+                    atomicMax(&sl->cmax_key, lvae_float_key(norm_max));
+                    if (FRAG) atomicAdd(&sl->norm_sum, (double)norm_acc);
                 }
             }
         }
@@ -257,9 +258,9 @@ __global__ void __launch_bounds__(1024)
 prep_operand_kernel(const float* __restrict__ x, const float* __restrict__ spread, int spread_kind,
                     int64_t n, int64_t npad, int D, int DP, PairHeader* hdr, double inv_ngauss,
                     float* __restrict__ out, float* __restrict__ bias, float* __restrict__ dparams,
-                    int DC, int rb) {
+                    int DC, int rb, float cond_floor) {
     prep_rows<SRC, FRAG>(blockIdx.x, rb, x, spread, spread_kind, n, npad, D, DP, hdr, inv_ngauss, out, bias,
-                         dparams, DC);
+                         dparams, DC, cond_floor);
 }
 
 // Both operands of a small log q(z) problem in one launch (one 32-row block per workgroup: many small workgroups
@@ -386,13 +387,32 @@ __global__ void prep_dparams_kernel(const float* __restrict__ mu, const float* _
 // redone anyway, so the fixed-reference pass is switched off for this call (lse_skip).
 __global__ void __launch_bounds__(256) lse_shift_bias_kernel(float* __restrict__ rbias, int64_t n, int64_t n_valid,
                                                              PairHeader* hdr) {
-    const float cmax = lvae_key_float(hdr->cmax_key);
+    // every workgroup folds the LVAE_NORM_SLOTS slots itself (one wave, one slot per lane: 8 KB out of L2)
+    __shared__ float sm_cmax;
+    __shared__ double sm_sum;
+    if (threadIdx.x < 64) {
+        static_assert(LVAE_NORM_SLOTS == 64, "one slot per lane of the first wave");
+        unsigned key = hdr->slot[threadIdx.x].cmax_key;
+        double ns = hdr->slot[threadIdx.x].norm_sum;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned ko = (unsigned)__shfl_xor((int)key, o, 64);
+            key = ko > key ? ko : key;
+        }
+        ns = wave_sum_d(ns);
+        if (threadIdx.x == 0) {
+            sm_cmax = lvae_key_float(key);
+            sm_sum = ns;
+        }
+    }
+    __syncthreads();
+    const float cmax = sm_cmax;
     const float ref = cmax - LSE_HEADROOM;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) rbias[i] -= ref;          // padding rows stay -inf
     if (i == 0) {
         hdr->lse_ref = ref;
-        const float mean = (float)(hdr->norm_sum / (double)n_valid);
+        const float mean = (float)(sm_sum / (double)n_valid);
         hdr->lse_skip = (cmax - mean > LSE_SKIP_SPREAD) ? 1u : 0u;
     }
 }
@@ -540,7 +560,7 @@ int lvae_launch_colsum(const float* mu, int64_t n, int D, PairHeader* hdr, hipSt
 
 int lvae_launch_prep(int src, bool frag, const float* x, const float* spread, int spread_kind,
                      int64_t n, int64_t npad, int D, int DP, PairHeader* hdr, int64_t ngauss,
-                     float* out, float* bias, float* dparams, int DC, hipStream_t st) {
+                     float* out, float* bias, float* dparams, int DC, hipStream_t st, float cond_floor) {
     const int threads = 32 * (DP / 4);
     int rb = PREP_RB;
     if (getenv("LVAE_PREP_RB")) rb = atoi(getenv("LVAE_PREP_RB")) > 0 ? atoi(getenv("LVAE_PREP_RB")) : rb;   // (sweeps)
@@ -548,7 +568,7 @@ int lvae_launch_prep(int src, bool frag, const float* x, const float* spread, in
     const double inv = 1.0 / (double)ngauss;
 #define LVAE_PREP(S, F)                                                                          \
     hipLaunchKernelGGL((prep_operand_kernel<S, F>), grid, dim3(threads), 0, st, x, spread,        \
-                       spread_kind, n, npad, D, DP, hdr, inv, out, bias, dparams, DC, rb)
+                       spread_kind, n, npad, D, DP, hdr, inv, out, bias, dparams, DC, rb, cond_floor)
     if (src == 3 && frag) LVAE_PREP(3, true);
     else if (src == 4 && !frag) LVAE_PREP(4, false);
     else if (src == 0 && frag) LVAE_PREP(0, true);
