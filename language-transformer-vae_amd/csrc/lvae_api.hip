@@ -19,7 +19,8 @@ int lvae_launch_prep_dparams(const float* mu, const float* spread, int spread_ki
                              hipStream_t st);
 int lvae_launch_prep_pair(const float* mu, const float* spread, int spread_kind, int64_t n, int64_t npad_r,
                           const float* z, int64_t m, int64_t npad_c, int D, int DP, PairHeader* hdr, float* rfrag,
-                          float* rbias, float* dparams, int DC, float* cop, float cond_floor, hipStream_t st);
+                          float* rbias, float* dparams, int DC, float* cop, float cond_floor, hipStream_t st,
+                          bool want_norm = false);
 int lvae_launch_finalize_small(const float2* partial_a, int nsplit_a, const float2* partial_b, int nsplit_b,
                                int64_t cpad, int64_t C, float log_norm, float* out, float* out_max, float* out_sum,
                                const PairHeader* hdr, float cond_limit, const float* z, const float* mu,
@@ -28,7 +29,9 @@ int lvae_launch_finalize(const float2* partial, int nsplit, int64_t cpad, int64_
                          const float* colbias, float log_norm, float* out, float* out_max,
                          float* out_sum, const PairHeader* hdr, float cond_limit, int use_if_above,
                          int use_ref, int* flags_out, const int* flags_in, int group_cols, hipStream_t st);
-int lvae_launch_lse_shift_bias(float* rbias, int64_t n, int64_t n_valid, PairHeader* hdr, hipStream_t st);
+int lvae_launch_lse_shift_bias(float* rbias, int64_t n, int64_t n_valid, PairHeader* hdr, hipStream_t st,
+                               const float* dp_mu = nullptr, const float* dp_spread = nullptr, int spread_kind = 0,
+                               int64_t dp_n = 0, int D = 0, int DC = 0, float* dparams = nullptr, float cond_limit = 0.f);
 int lvae_launch_finalize_pm(const float2* partial, int nsplit, int64_t cpad, int64_t C, int D, int DC,
                             float log_norm, float* tmp, float* out, hipStream_t st);
 int lvae_launch_pair_lse_mfma(const PairPlan& p, const float* rfrag, const float* rbias,
@@ -57,7 +60,8 @@ int lvae_launch_iw_lse(const float* a, const float* b, const float* c, int64_t B
 
 int lvae_launch_latent_sums(const float* z, const float* mu, const float* logvar, const float* log_qz,
                             const float* log_qz_pm, int64_t M, int D, double* sums, hipStream_t st,
-                            bool sums_are_zero = false);
+                            bool sums_are_zero = false, const LateMerge* late = nullptr);
+bool lvae_latent_sums_vec(int D);
 
 int lvae_launch_pair_mfma(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                           float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
@@ -391,15 +395,24 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     const bool auto_gate = want_joint && joint_path == LVAE_PATH_AUTO;
     const bool dparams_now = with_pm || (want_joint && joint_path == LVAE_PATH_DIRECT);
     // (the redo flags of the fixed-reference pass sit right behind the header: one fill for both)
+    // (AUTO path with the fixed-reference pass: the gated direct-form parameters ride on the bias-shift launch)
+    const bool dparams_with_shift = need_direct && !dparams_now && auto_gate && need_mfma && N <= (1LL << 24) && p.DP;
     const size_t clear_bytes = need_mfma ? p.off_redo - p.off_hdr + (size_t)(p.cpad / 128 + 1) * sizeof(int)
                                          : sizeof(PairHeader);
     if (p.DP) {
         rc = clear_and_colsum(mu, N, D, hdr, clear_bytes, st, tail ? tail->sums : nullptr);   // (also zeroes the statistics)
         if (rc) return rc;
         // (gated calls only compare the conditioning estimate with the limit: workgroups below it publish nothing)
-        rc = lvae_launch_prep(0, true, mu, spread, spread_kind, N, p.nblk * 32, D, p.DP, hdr, N,
-                              bx ? nullptr : rfrag, rbias, dparams_now ? dparams : nullptr, p.DC, st,
-                              auto_gate ? LVAE_COND_LIMIT : -1.f);
+        // fp32 contraction: both operands in ONE launch (one 32-row block per workgroup, posterior rows first)
+        const bool prep_both = need_mfma && !bx && !getenv("LVAE_PREP_RB");
+        if (prep_both)
+            rc = lvae_launch_prep_pair(mu, spread, spread_kind, N, p.nblk * 32, z, M, p.cpad, D, p.DP, hdr, rfrag, rbias,
+                                       dparams_now ? dparams : nullptr, p.DC, cop, auto_gate ? LVAE_COND_LIMIT : -1.f, st,
+                                       true);
+        else
+            rc = lvae_launch_prep(0, true, mu, spread, spread_kind, N, p.nblk * 32, D, p.DP, hdr, N,
+                                  bx ? nullptr : rfrag, rbias, dparams_now ? dparams : nullptr, p.DC, st,
+                                  auto_gate ? LVAE_COND_LIMIT : -1.f);
         if (rc) return rc;
         if (bx && need_mfma) {   // limb operands into the same regions (the fp32 prep above still owns bias + header)
             rc = lvae_launch_prep_bf16x3(0, true, mu, spread, spread_kind, N, p.nblk * 32, D, p.DP, hdr, N,
@@ -408,12 +421,12 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
             rc = lvae_launch_prep_bf16x3(1, false, z, nullptr, 0, M, p.cpad, D, p.DP, hdr, N, cop, st);
             if (rc) return rc;
         }
-        if (need_direct && !dparams_now) {
+        if (need_direct && !dparams_now && !dparams_with_shift) {
             rc = lvae_launch_prep_dparams(mu, spread, spread_kind, N, D, p.DC, dparams,
                                           auto_gate ? hdr : nullptr, LVAE_COND_LIMIT, st);
             if (rc) return rc;
         }
-        if (need_mfma && !bx) {
+        if (need_mfma && !bx && !prep_both) {
             rc = lvae_launch_prep(1, false, z, nullptr, 0, M, p.cpad, D, p.DP, hdr, N, cop, nullptr,
                                   nullptr, p.DC, st);
             if (rc) return rc;
@@ -430,11 +443,19 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     // the largest row bias), then -- for the rare columns whose total underflowed that reference -- a
     // redo of their workgroups with the running-maximum kernel.  All decided on the device.
     const bool fixed_ref = need_mfma && N <= (1LL << 24);
+    // The statistics call folds the redo merge, the direct-form merge and the float64 sums into one launch
+    // (LateMerge): three launches fewer, two of them gates that exit at once on ordinary inputs.
+    const bool fuse_tail = tail && want_joint && !with_pm && fixed_ref && lvae_latent_sums_vec(D) &&
+                           !getenv("LVAE_NO_FUSED_TAIL");
     int* redo = (int*)(base + p.off_redo);
     const int group_cols = 128 * p.NCB;
     if (need_mfma) {
         if (fixed_ref) {
-            rc = lvae_launch_lse_shift_bias(rbias, p.nblk * 32, N, hdr, st);
+            if (dparams_with_shift)
+                rc = lvae_launch_lse_shift_bias(rbias, p.nblk * 32, N, hdr, st, mu, spread, spread_kind, N, D, p.DC,
+                                                dparams, LVAE_COND_LIMIT);
+            else
+                rc = lvae_launch_lse_shift_bias(rbias, p.nblk * 32, N, hdr, st);
             if (rc) return rc;
         }
     }
@@ -475,12 +496,14 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
                 rc = launch_pair(p, rfrag, rbias, cop, partial, hdr, limit, 0, exclude_diag != 0, diag_offset, 0,
                                  redo, 0, nullptr, st);
                 if (rc) return rc;
-                rc = lvae_launch_finalize(partial, p.nsplit, p.cpad, M, nullptr, log_norm, log_qz, row_max,
-                                          row_sum, hdr, limit, 0, 1, nullptr, redo, group_cols, st);
-                if (rc) return rc;
+                if (!fuse_tail) {
+                    rc = lvae_launch_finalize(partial, p.nsplit, p.cpad, M, nullptr, log_norm, log_qz, row_max,
+                                              row_sum, hdr, limit, 0, 1, nullptr, redo, group_cols, st);
+                    if (rc) return rc;
+                }
             }
         }
-        if (joint_path != LVAE_PATH_MFMA) {
+        if (joint_path != LVAE_PATH_MFMA && !fuse_tail) {
             rc = lvae_launch_finalize(dpartial, p.dsplit, p.cpad, M, nullptr, log_norm, log_qz, row_max,
                                       row_sum, hdr, limit, 1, 0, nullptr, nullptr, group_cols, st);
             if (rc) return rc;
@@ -490,6 +513,22 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
         rc = lvae_launch_finalize_pm(dpartial_pm, p.dsplit, p.cpad, M, D, p.DC, log_norm,
                                      (float*)(base + p.off_pmtmp), log_qz_pm, st);
         if (rc) return rc;
+    }
+    if (tail && fuse_tail) {
+        LateMerge lm{};
+        lm.partial_a = partial;
+        lm.nsplit_a = p.nsplit;
+        lm.partial_b = joint_path != LVAE_PATH_MFMA ? dpartial : nullptr;
+        lm.nsplit_b = p.dsplit;
+        lm.hdr = hdr;
+        lm.flags = redo;
+        lm.out = log_qz;
+        lm.cpad = p.cpad;
+        lm.group_cols = group_cols;
+        lm.use_ref_a = 1;
+        lm.cond_limit = limit;
+        lm.log_norm = log_norm;
+        return lvae_launch_latent_sums(z, tail->mu, tail->logvar, log_qz, nullptr, M, D, tail->sums, st, true, &lm);
     }
     if (tail) return lvae_launch_latent_sums(z, tail->mu, tail->logvar, log_qz, log_qz_pm, M, D, tail->sums, st, p.DP != 0);
     return LVAE_OK;

@@ -48,6 +48,22 @@ struct PairHeader {
     NormSlot slot[LVAE_NORM_SLOTS];
 };
 
+// Late merge folded into latent_sums_kernel (the statistics call): rows whose fixed-reference total underflowed take
+// the redo pass's partials (source a: running-maximum pairs, + the reference the biases were shifted by), and when
+// the conditioning gate chose the direct form every row takes the direct kernel's partials (source b) -- the
+// arithmetic of finalize_lse_kernel, in the launch that reads log q(z) anyway instead of two launches of its own.
+struct LateMerge {
+    const float2* partial_a;   // [nsplit_a][cpad]
+    const float2* partial_b;   // [nsplit_b][cpad] or NULL
+    const PairHeader* hdr;
+    const int* flags;          // redo flag per group_cols kept elements
+    float* out;                // log q(z) [M]: rewritten for merged rows
+    int64_t cpad;
+    int nsplit_a, nsplit_b, group_cols, use_ref_a, enabled;
+    float cond_limit;          // < 0: no gate (source a only)
+    float log_norm;
+};
+
 // Arguments of the label-permutation mode of the MFMA pair kernel (MMD permutation test).
 struct PermArgs {
     const void* labfrag;             // [nblk][4 perm tiles][2 steps][64 lanes][8 bf16] (prep_labels_kernel)

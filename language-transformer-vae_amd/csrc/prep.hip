@@ -270,10 +270,11 @@ __global__ void __launch_bounds__(1024)
 prep_pair_kernel(const float* __restrict__ mu, const float* __restrict__ spread, int spread_kind, int64_t n,
                  int64_t npad_r, const float* __restrict__ z, int64_t m, int64_t npad_c, int D, int DP,
                  PairHeader* hdr, double inv_ngauss, float* __restrict__ rfrag, float* __restrict__ rbias,
-                 float* __restrict__ dparams, int DC, float* __restrict__ cop, int64_t wg_gauss, float cond_floor) {
+                 float* __restrict__ dparams, int DC, float* __restrict__ cop, int64_t wg_gauss, float cond_floor,
+                 int want_norm) {
     if ((int64_t)blockIdx.x < wg_gauss)
         prep_rows<0, true>(blockIdx.x, 1, mu, spread, spread_kind, n, npad_r, D, DP, hdr, inv_ngauss, rfrag, rbias,
-                           dparams, DC, cond_floor, false);
+                           dparams, DC, cond_floor, want_norm != 0);
     else
         prep_rows<1, false>((int64_t)blockIdx.x - wg_gauss, 1, z, nullptr, 0, m, npad_c, D, DP, hdr, inv_ngauss, cop,
                             nullptr, nullptr, DC);
@@ -357,12 +358,21 @@ int lvae_launch_finalize_ksum_multi(const double* const* partial, const int* nsp
 
 // Direct-path parameters only (used when the MFMA path is not available for this D).
 // gate_hdr != NULL: only when the conditioning estimate selects the direct path (cond > cond_limit).
+__device__ __forceinline__ void dparams_element(const float* __restrict__ mu, const float* __restrict__ spread,
+                                                int spread_kind, int64_t n, int D, int DC,
+                                                float* __restrict__ dparams, int64_t idx);
+
 __global__ void prep_dparams_kernel(const float* __restrict__ mu, const float* __restrict__ spread,
                                     int spread_kind, int64_t n, int D, int DC,
                                     float* __restrict__ dparams, const PairHeader* __restrict__ gate_hdr,
                                     float cond_limit) {
     if (gate_hdr && !(__uint_as_float(gate_hdr->cond_bits) > cond_limit)) return;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    dparams_element(mu, spread, spread_kind, n, D, DC, dparams, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+__device__ __forceinline__ void dparams_element(const float* __restrict__ mu, const float* __restrict__ spread,
+                                                int spread_kind, int64_t n, int D, int DC,
+                                                float* __restrict__ dparams, int64_t idx) {
     if (idx >= n * DC) return;
     const int64_t row = idx / DC;
     const int d = (int)(idx - row * DC);
@@ -385,8 +395,20 @@ __global__ void prep_dparams_kernel(const float* __restrict__ mu, const float* _
 // A sample's total is dominated by posteriors with a typical normaliser; if the mean normaliser is more
 // than LSE_SKIP_SPREAD bits below the largest one, almost every column would come out below the floor and be
 // redone anyway, so the fixed-reference pass is switched off for this call (lse_skip).
+// Workgroups from `shift_blocks` on (AUTO path only) write the direct-form parameters iff the conditioning estimate
+// selects the direct path -- the gated prep_dparams_kernel riding on this launch instead of one of its own.
 __global__ void __launch_bounds__(256) lse_shift_bias_kernel(float* __restrict__ rbias, int64_t n, int64_t n_valid,
-                                                             PairHeader* hdr) {
+                                                             PairHeader* hdr, unsigned shift_blocks,
+                                                             const float* __restrict__ dp_mu,
+                                                             const float* __restrict__ dp_spread, int spread_kind,
+                                                             int64_t dp_n, int D, int DC, float* __restrict__ dparams,
+                                                             float cond_limit) {
+    if (blockIdx.x >= shift_blocks) {
+        if (!(__uint_as_float(hdr->cond_bits) > cond_limit)) return;
+        dparams_element(dp_mu, dp_spread, spread_kind, dp_n, D, DC, dparams,
+                        (int64_t)(blockIdx.x - shift_blocks) * 256 + threadIdx.x);
+        return;
+    }
     // every workgroup folds the LVAE_NORM_SLOTS slots itself (one wave, one slot per lane: 8 KB out of L2)
     __shared__ float sm_cmax;
     __shared__ double sm_sum;
@@ -584,11 +606,13 @@ int lvae_launch_prep(int src, bool frag, const float* x, const float* spread, in
 
 int lvae_launch_prep_pair(const float* mu, const float* spread, int spread_kind, int64_t n, int64_t npad_r,
                           const float* z, int64_t m, int64_t npad_c, int D, int DP, PairHeader* hdr, float* rfrag,
-                          float* rbias, float* dparams, int DC, float* cop, float cond_floor, hipStream_t st) {
+                          float* rbias, float* dparams, int DC, float* cop, float cond_floor, hipStream_t st,
+                          bool want_norm) {
     const int threads = 32 * (DP / 4);
     const int64_t wg_r = npad_r / 32, wg_c = npad_c / 32;
     hipLaunchKernelGGL(prep_pair_kernel, dim3((unsigned)(wg_r + wg_c)), dim3(threads), 0, st, mu, spread, spread_kind, n,
-                       npad_r, z, m, npad_c, D, DP, hdr, 1.0 / (double)n, rfrag, rbias, dparams, DC, cop, wg_r, cond_floor);
+                       npad_r, z, m, npad_c, D, DP, hdr, 1.0 / (double)n, rfrag, rbias, dparams, DC, cop, wg_r, cond_floor,
+                       want_norm ? 1 : 0);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }
@@ -614,9 +638,14 @@ int lvae_launch_finalize(const float2* partial, int nsplit, int64_t cpad, int64_
     return LVAE_OK;
 }
 
-int lvae_launch_lse_shift_bias(float* rbias, int64_t n, int64_t n_valid, PairHeader* hdr, hipStream_t st) {
-    hipLaunchKernelGGL(lse_shift_bias_kernel, dim3((unsigned)lvae_ceil_div(n, 256)), dim3(256), 0, st, rbias, n,
-                       n_valid, hdr);
+// dp_mu != NULL: also the gated direct-form parameters (dp_n posteriors), see the kernel.
+int lvae_launch_lse_shift_bias(float* rbias, int64_t n, int64_t n_valid, PairHeader* hdr, hipStream_t st,
+                               const float* dp_mu, const float* dp_spread, int spread_kind, int64_t dp_n, int D, int DC,
+                               float* dparams, float cond_limit) {
+    const unsigned shift_blocks = (unsigned)lvae_ceil_div(n, 256);
+    const unsigned dp_blocks = dp_mu ? (unsigned)lvae_ceil_div(dp_n * DC, 256) : 0u;
+    hipLaunchKernelGGL(lse_shift_bias_kernel, dim3(shift_blocks + dp_blocks), dim3(256), 0, st, rbias, n,
+                       n_valid, hdr, shift_blocks, dp_mu, dp_spread, spread_kind, dp_n, D, DC, dparams, cond_limit);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }

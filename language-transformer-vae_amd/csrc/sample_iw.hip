@@ -475,8 +475,24 @@ __global__ void __launch_bounds__(256)
 latent_sums_kernel(const float* __restrict__ z, const float* __restrict__ mu,
                    const float* __restrict__ logvar, const float* __restrict__ log_qz,
                    const float* __restrict__ log_qz_pm, int64_t M, int D, int G,
-                   double* __restrict__ sums) {
+                   double* __restrict__ sums, const LateMerge lm) {
     double a_lq = 0.0, a_pm = 0.0, a_lp = 0.0, a_lqx = 0.0;
+    // late merge (G > 0 only, see LateMerge): which rows take which partials
+    const bool lm_b = lm.enabled && lm.partial_b && lm.cond_limit >= 0.f &&
+                      __uint_as_float(lm.hdr->cond_bits) > lm.cond_limit;
+    auto merged_row = [&](int64_t i) -> float {
+        const float2* __restrict__ partial = lm_b ? lm.partial_b : lm.partial_a;
+        const int nsplit = lm_b ? lm.nsplit_b : lm.nsplit_a;
+        float mx = -INFINITY;
+        for (int k = 0; k < nsplit; ++k) mx = fmaxf(mx, partial[k * lm.cpad + i].x);
+        double s = 0.0;
+        for (int k = 0; k < nsplit; ++k) {
+            const float2 p = partial[k * lm.cpad + i];
+            if (p.y > 0.f) s += (double)p.y * (double)(p.x == mx ? 1.0f : lvae_exp2(p.x - mx));
+        }
+        const double cb = (!lm_b && lm.use_ref_a) ? (double)lm.hdr->lse_ref : 0.0;
+        return (float)(((double)mx + log2(s) + cb) * LVAE_LN2 - (double)lm.log_norm);
+    };
     if (G > 0) {
         const int gl = threadIdx.x % G;
         const int64_t rows_per_pass = (int64_t)gridDim.x * (256 / G);
@@ -500,7 +516,13 @@ latent_sums_kernel(const float* __restrict__ z, const float* __restrict__ mu,
             if (ok && gl == 0) {
                 a_lqx += (double)lq;
                 a_lp += (double)lp;
-                if (log_qz) a_lq += (double)log_qz[row];
+                if (lm.enabled && (lm_b || lm.flags[row / lm.group_cols] != 0)) {
+                    const float v = merged_row(row);
+                    lm.out[row] = v;
+                    a_lq += (double)v;
+                } else if (log_qz) {
+                    a_lq += (double)log_qz[row];
+                }
                 if (log_qz_pm) a_pm += (double)log_qz_pm[row];
             }
         }
@@ -660,18 +682,29 @@ int lvae_launch_finalize_small(const float2* partial_a, int nsplit_a, const floa
     return LVAE_OK;
 }
 
+bool lvae_latent_sums_vec(int D) {
+    int G = 0;
+    return vec_ok(D, &G);
+}
+
 int lvae_launch_latent_sums(const float* z, const float* mu, const float* logvar, const float* log_qz,
                             const float* log_qz_pm, int64_t M, int D, double* sums, hipStream_t st,
-                            bool sums_are_zero) {
+                            bool sums_are_zero, const LateMerge* late) {
     int G = 0;
     if (!vec_ok(D, &G)) G = 0;
+    LateMerge lm{};
+    if (late) {
+        if (!G) return lvae_set_error(LVAE_ERR_INVALID, "late merge needs the vector layout (D a multiple of 4)");
+        lm = *late;
+        lm.enabled = 1;
+    }
     const int64_t rows_per_block = G ? 256 / G : 256;
     int64_t blocks = lvae_ceil_div(M, rows_per_block);
     if (blocks > 512) blocks = 512;      // four float64 atomics per block land on the same four words (C2: 17.4 us at 1,024 blocks, 12.1 at 512, 12.7 at 256)
     // (sums_are_zero: an earlier kernel of the same call cleared them -- no fill packet ahead of this launch)
     if (!sums_are_zero) LVAE_HIP(hipMemsetAsync(sums, 0, 5 * sizeof(double), st));
     hipLaunchKernelGGL(latent_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, st, z, mu, logvar, log_qz,
-                       log_qz_pm, M, D, G, sums);
+                       log_qz_pm, M, D, G, sums, lm);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }
