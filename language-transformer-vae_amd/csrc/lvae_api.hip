@@ -301,10 +301,11 @@ struct StatsTail {
 };
 
 // Largest N * M served by the small path (five launches, running-maximum epilogue in one pass: its lower MFMA rate
-// costs less than the shift / redo / second-merge launches of the fixed-reference form up to ~12,600^2 -- measured,
-// tools/sweep_small_threshold.py, D = 32: 48 vs 76 us at 4,096^2, 109 vs 127 at 8,192^2, 213 vs 229 at 12,288^2,
-// 326 vs 322 at 16,384^2), and the most samples its merge handles.
-#define LVAE_SMALL_PAIRS 160000000.0
+// costs less than the extra launches of the fixed-reference form -- nine since the launch-chain fusions -- up to
+// ~8,000^2; measured, tools/sweep_small_threshold.py, D = 32, small vs general: 48 vs 60 us at 4,096^2, 78 vs 81 at
+// 6,144^2, 110 vs 110 at 8,192^2, 213 vs 200 at 12,288^2, 328 vs 303 at 16,384^2), and the most samples its merge
+// handles.
+#define LVAE_SMALL_PAIRS 60000000.0
 #define LVAE_SMALL_MAX_M 16384
 
 // Shared driver: samples on the kept axis, posteriors on the reduced axis.
