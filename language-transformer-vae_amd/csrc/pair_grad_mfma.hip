@@ -48,7 +48,7 @@ bwd_prep_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, 
                 const float* __restrict__ g, int64_t M, int D, int DP, PairHeader* hdr, int64_t nblk_j,
                 float* __restrict__ rec_j, float* __restrict__ colop_j, float* __restrict__ colbias_j,
                 float* __restrict__ rec_i, float* __restrict__ colop_i, float* __restrict__ colbias_i,
-                float* __restrict__ colgb_j) {
+                float* __restrict__ colgb_j, float cond_floor) {
     __shared__ float p0[32 * 129], p1[32 * 129];
     __shared__ float sm_shift[128], sm_gb[16 * 32], sm_bias[32], sm_g[32];
     __shared__ float sm_cond[4];
@@ -109,7 +109,9 @@ bwd_prep_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, 
     __syncthreads();
     if (post && tid == 0) {      // error scale of the grouped accumulation: the largest group, sqrt(groups) of them
         const float c = fmaxf(fmaxf(sm_cond[0], sm_cond[1]), fmaxf(sm_cond[2], sm_cond[3])) * sqrtf((float)G);
-        atomicMax(&hdr->cond_bits, __float_as_uint(c));
+        // (the estimate is only ever compared with the gate's limit: workgroups at or below it publish nothing --
+        //  one device-scope atomic per workgroup on a single word was the larger half of this launch)
+        if (c > cond_floor) atomicMax(&hdr->cond_bits, __float_as_uint(c));
     }
     float* __restrict__ rec = (post ? rec_j : rec_i) + blk * (int64_t)BWD_REC_F(DP);
     float* __restrict__ cop = (post ? colop_j : colop_i) + blk * 32 * (int64_t)(2 * DP);
@@ -420,7 +422,7 @@ int lvae_launch_bwd_mfma(const BwdMfmaLayout& L, void* ws, const float* z, const
     hipLaunchKernelGGL(bwd_prep_kernel, dim3((unsigned)(nbj + nbi)), dim3(256), 0, st, mu, logvar, N, z, log_qz, log_norm,
                        g, M, D, L.DP, hdr, nbj, (float*)(base + L.off_recj), (float*)(base + L.off_colj),
                        (float*)(base + L.off_cbj), (float*)(base + L.off_reci), (float*)(base + L.off_coli),
-                       (float*)(base + L.off_cbi), (float*)(base + L.off_cgj));
+                       (float*)(base + L.off_cbi), (float*)(base + L.off_cgj), cond_limit >= 0.f ? cond_limit : INFINITY);
     const bool want_z = d_z != nullptr, want_p = d_mu || d_logvar;
     switch (L.DP) {
         case 16: launch_sweeps<16, 2>(L, base, M, N, g, want_p, hdr, cond_limit, st); break;
