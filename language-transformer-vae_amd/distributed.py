@@ -248,7 +248,7 @@ def sharded_iw_log_p_x(mu_local, logvar_local, eps_local, log_p_x_z_local, group
     DistributedSampler split at dist_iw_...py:86-87); the optional all-gather of the [B_r] results
     replaces the reference's pickle concatenation (:48-73)."""
     from . import estimators as E
-    iw = E.reparam_iw(mu_local, logvar_local, eps_local, log_p_x_z_local, return_z=False)["iw_ll"]
+    iw = E.reparam_iw(mu_local, logvar_local, eps_local, log_p_x_z_local, return_z=False, return_densities=False)["iw_ll"]
     if not gather:
         return iw
     out, _ = all_gather_rows(iw.reshape(-1, 1), group)

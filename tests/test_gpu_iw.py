@@ -99,6 +99,9 @@ def test_reparam_iw_row_geometries(D):
             np.testing.assert_allclose(out["log_q_z_x"].cpu().numpy(), lq, rtol=1e-4, atol=1e-3, err_msg=f"K={K}")
             np.testing.assert_allclose(out["log_p_z"].cpu().numpy(), lp, rtol=1e-4, atol=1e-3, err_msg=f"K={K}")
             np.testing.assert_allclose(out["iw_ll"].cpu().numpy(), iw, rtol=1e-4, atol=1e-3, err_msg=f"K={K}")
+        only = E.reparam_iw(dev(mu), dev(lv), dev(eps), dev(lpxz), return_z=False, return_densities=False)
+        assert only["log_q_z_x"] is None and only["log_p_z"] is None and only["latent_z"] is None
+        np.testing.assert_allclose(only["iw_ll"].cpu().numpy(), iw, rtol=1e-4, atol=1e-3)
         # densities of given z (no reparameterisation): the same row reduction with z as the source
         lq2 = E.sample_log_likelihood(dev(z), dev(mu), dev(lv), reduce_batch_dim=False)
         np.testing.assert_allclose(lq2.cpu().numpy(), lq, rtol=1e-4, atol=1e-3)

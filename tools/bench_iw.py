@@ -19,7 +19,9 @@ for B, K, D in ((16384, 1000, 32), (16384, 600, 32), (4096, 1000, 64), (65536, 1
     eps = torch.randn(B, K, D, device="cuda", generator=g); lpxz = 5 * torch.randn(B, K, device="cuda", generator=g) - 100
     t = timed(lambda: E.reparam_iw(mu, lv, eps, lpxz, return_z=False))
     by = B * K * (4 * D + 4 + 8)      # eps + log_p_x_z read, log_q_z_x + log_p_z written
+    t0 = timed(lambda: E.reparam_iw(mu, lv, eps, lpxz, return_z=False, return_densities=False))
+    by0 = B * K * (4 * D + 4)          # the reduction alone: eps + log_p_x_z read, iw_ll [B] written
     t2 = timed(lambda: E.reparam_iw(mu, lv, eps, lpxz, return_z=True))
     by2 = B * K * (8 * D + 4 + 8)
-    print(f"B={B} K={K} D={D}: no-z {t*1e3:.3f} ms {by/t/1e9:.0f} GB/s ({by/t/8e12*100:.1f}%)   +z {t2*1e3:.3f} ms {by2/t2/1e9:.0f} GB/s ({by2/t2/8e12*100:.1f}%)", flush=True)
+    print(f"B={B} K={K} D={D}: iw_ll only {t0*1e3:.3f} ms {by0/t0/1e9:.0f} GB/s ({by0/t0/8e12*100:.1f}%)   no-z {t*1e3:.3f} ms {by/t/1e9:.0f} GB/s ({by/t/8e12*100:.1f}%)   +z {t2*1e3:.3f} ms {by2/t2/1e9:.0f} GB/s ({by2/t2/8e12*100:.1f}%)", flush=True)
     del eps, lpxz
