@@ -446,7 +446,8 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     const bool fixed_ref = need_mfma && N <= (1LL << 24);
     // The statistics call folds the redo merge, the direct-form merge and the float64 sums into one launch
     // (LateMerge): three launches fewer, two of them gates that exit at once on ordinary inputs.
-    const bool fuse_tail = tail && want_joint && !with_pm && fixed_ref && lvae_latent_sums_vec(D) &&
+    // Without the statistics (lvae_log_qz_f32) the same kernel runs as the late merge alone: one launch for both merges.
+    const bool fuse_tail = log_qz && !row_max && fixed_ref && (tail ? !with_pm : true) && lvae_latent_sums_vec(D) &&
                            !getenv("LVAE_NO_FUSED_TAIL");
     int* redo = (int*)(base + p.off_redo);
     const int group_cols = 128 * p.NCB;
@@ -515,7 +516,7 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
                                      (float*)(base + p.off_pmtmp), log_qz_pm, st);
         if (rc) return rc;
     }
-    if (tail && fuse_tail) {
+    if (fuse_tail) {
         LateMerge lm{};
         lm.partial_a = partial;
         lm.nsplit_a = p.nsplit;
@@ -529,6 +530,7 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
         lm.use_ref_a = 1;
         lm.cond_limit = limit;
         lm.log_norm = log_norm;
+        if (!tail) return lvae_launch_latent_sums(nullptr, nullptr, nullptr, log_qz, nullptr, M, D, nullptr, st, true, &lm);
         return lvae_launch_latent_sums(z, tail->mu, tail->logvar, log_qz, nullptr, M, D, tail->sums, st, true, &lm);
     }
     if (tail) return lvae_launch_latent_sums(z, tail->mu, tail->logvar, log_qz, log_qz_pm, M, D, tail->sums, st, p.DP != 0);

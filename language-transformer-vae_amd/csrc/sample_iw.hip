@@ -507,7 +507,7 @@ latent_sums_kernel(const float* __restrict__ z, const float* __restrict__ mu,
             const int64_t row = base + threadIdx.x / G;
             const bool ok = row < M;
             float lq = 0.f, lp = 0.f;
-            if (ok) {
+            if (ok && sums) {       // (sums == NULL: the late merge alone, lvae_log_qz_f32)
                 const f32x4 zz = *reinterpret_cast<const f32x4*>(z + row * D + 4 * gl);
                 const f32x4 mm = *reinterpret_cast<const f32x4*>(mu + row * D + 4 * gl);
                 const f32x4 lv = *reinterpret_cast<const f32x4*>(logvar + row * D + 4 * gl);
@@ -548,6 +548,7 @@ latent_sums_kernel(const float* __restrict__ z, const float* __restrict__ mu,
             if (log_qz_pm) a_pm += (double)log_qz_pm[row];
         }
     }
+    if (!sums) return;
     __shared__ double sm[4][4];
     a_lq = wave_sum_d(a_lq);
     a_pm = wave_sum_d(a_pm);
@@ -709,7 +710,8 @@ int lvae_launch_latent_sums(const float* z, const float* mu, const float* logvar
     int64_t blocks = lvae_ceil_div(M, rows_per_block);
     if (blocks > 512) blocks = 512;      // four float64 atomics per block land on the same four words (C2: 17.4 us at 1,024 blocks, 12.1 at 512, 12.7 at 256)
     // (sums_are_zero: an earlier kernel of the same call cleared them -- no fill packet ahead of this launch)
-    if (!sums_are_zero) LVAE_HIP(hipMemsetAsync(sums, 0, 5 * sizeof(double), st));
+    if (!sums && !late) return lvae_set_error(LVAE_ERR_INVALID, "latent sums: nothing to do");
+    if (sums && !sums_are_zero) LVAE_HIP(hipMemsetAsync(sums, 0, 5 * sizeof(double), st));
     hipLaunchKernelGGL(latent_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, st, z, mu, logvar, log_qz,
                        log_qz_pm, M, D, G, sums, lm);
     LVAE_LAUNCH_CHECK();

@@ -62,3 +62,29 @@ def test_fused_tail_sources(kind, D, monkeypatch):
     lqx = onp.sample_log_likelihood(z, mu_l, lv_l, reduce_batch_dim=False).astype(np.float64).sum()
     lp = onp.sample_log_likelihood(z, reduce_batch_dim=False).astype(np.float64).sum()
     assert abs(s_f[3] - lqx) <= 1e-5 * abs(lqx) and abs(s_f[2] - lp) <= 1e-5 * abs(lp)
+
+
+@pytest.mark.parametrize("kind", ["plain", "far", "peaked", "spread"])
+@pytest.mark.parametrize("pm", [False, True])
+def test_late_merge_of_the_plain_entry_point(kind, pm, monkeypatch):
+    """lvae_log_qz_f32 on the general path: the redo merge and the direct-form merge as ONE launch (the late merge
+    alone), bit-equal to the two-launch form, with and without the product of marginals."""
+    from lvae import estimators as E
+    rng = np.random.default_rng(hash((kind, pm)) % 2**31)
+    N, M, D = 600, 500, 32
+    mu, lv, z, _ = _case(kind, rng, N, M, D)
+    ref, refpm = onp.approximate_log_q_z(mu, lv, z, method="all", prod_marginals=True, reduce_mean=False)
+    monkeypatch.setenv("LVAE_NO_SMALL_PATH", "1")
+    out = {}
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("LVAE_NO_FUSED_TAIL", raising=False)
+        else:
+            monkeypatch.setenv("LVAE_NO_FUSED_TAIL", "1")
+        lq, lqpm = E.approximate_log_q_z(dev(mu), dev(lv), dev(z), method="all", prod_marginals=pm, reduce_mean=False)
+        out[fused] = (lq.cpu().numpy(), lqpm.cpu().numpy() if pm else None)
+    np.testing.assert_array_equal(out[True][0], out[False][0])
+    np.testing.assert_allclose(out[True][0], ref, rtol=0, atol=1e-4 * max(1.0, np.abs(ref).max()))
+    if pm:
+        np.testing.assert_array_equal(out[True][1], out[False][1])
+        np.testing.assert_allclose(out[True][1], refpm, rtol=0, atol=1e-4 * max(1.0, np.abs(refpm).max()))
