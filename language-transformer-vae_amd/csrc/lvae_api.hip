@@ -287,8 +287,10 @@ extern "C" int lvae_log_qz_workspace_bytes(int64_t M, int64_t N, int D, int with
     LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
     LVAE_CHECK_ARG(M >= 1 && N >= 1 && D >= 1 && D <= 4096, "bad shape M=%lld N=%lld D=%d",
                    (long long)M, (long long)N, D);
-    const PairPlan p = lvae_make_pair_plan(N, M, D, with_prod_marg != 0);
-    *out_bytes = (int64_t)p.total;
+    // (the layout depends on the contraction the call will choose: cover both)
+    const size_t a = lvae_log_qz_plan(N, M, D, with_prod_marg != 0, false).total;
+    const size_t b = lvae_log_qz_plan(N, M, D, with_prod_marg != 0, true).total;
+    *out_bytes = (int64_t)(a > b ? a : b);
     return LVAE_OK;
 }
 
@@ -322,7 +324,7 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     const bool bx = path == LVAE_PATH_MFMA_BF16X3;
     if (bx) path = LVAE_PATH_MFMA;          // same control flow as the forced fp32 MFMA path, other pair kernel
     const bool with_pm = log_qz_pm != nullptr;
-    const PairPlan p = lvae_make_pair_plan(N, M, D, with_pm);
+    const PairPlan p = lvae_log_qz_plan(N, M, D, with_pm, bx, exclude_diag != 0);
     rc = check_ws(ws, ws_bytes, p.total);
     if (rc) return rc;
     if (path == LVAE_PATH_MFMA && p.DP == 0)
@@ -550,7 +552,7 @@ extern "C" int lvae_latent_stats_f32(const float* z, const float* mu_all, const 
 extern "C" int lvae_plan_info(int64_t M, int64_t N, int D, int prod_marginals, int64_t* out) {
     LVAE_CHECK_ARG(out, "out is NULL");
     LVAE_CHECK_ARG(M >= 1 && N >= 1 && D >= 1, "need M, N, D >= 1");
-    const PairPlan p = lvae_make_pair_plan(N, M, D, prod_marginals != 0);
+    const PairPlan p = lvae_log_qz_plan(N, M, D, prod_marginals != 0, false);
     out[0] = p.DP; out[1] = p.NCB; out[2] = p.cpad; out[3] = p.nsplit; out[4] = p.blk_per_split;
     out[5] = p.dsplit; out[6] = p.nblk; out[7] = (int64_t)p.total;
     return LVAE_OK;
@@ -599,7 +601,8 @@ extern "C" int lvae_log_qz_noalloc_f32(const float* z, const float* mu, const fl
     LVAE_CHECK_ARG(log_qz || log_qz_prod_marg, "at least one of log_qz / log_qz_prod_marg is required");
     int rc = check_pair_shapes(z, mu, spread, spread_kind, M, N, D);
     if (rc) return rc;
-    const PairPlan p = lvae_make_pair_plan(N, M, D, log_qz_prod_marg != nullptr);
+    const PairPlan p = lvae_log_qz_plan(N, M, D, log_qz_prod_marg != nullptr, path == LVAE_PATH_MFMA_BF16X3,
+                                        exclude_diag != 0);
     if (p.total > (size_t)LVAE_NOALLOC_SCRATCH_BYTES)
         return lvae_set_error(LVAE_ERR_UNSUPPORTED,
                               "M=%lld, N=%lld, D=%d%s needs %zu bytes of scratch; the allocation-free entry point holds "

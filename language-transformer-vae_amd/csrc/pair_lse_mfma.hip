@@ -41,6 +41,29 @@ static int launch_t(const PairPlan& p, const float* rfrag, const float* rbias, c
 // sym != 0 (epi 1/2/3 only; the kept elements are rows excl_offset.. of the reduced sample, excl_offset a
 // multiple of 32): visit the upper
 // triangle of tiles only; the TOTAL over columns is that of the full matrix, the per-column sums are not.
+// D in (32, 64] with TWO column blocks per wave (220 registers, two waves per SIMD): the log q(z) plans of the fp32
+// path (lvae_log_qz_plan) -- 88.8 -> 89.9 % of peak at 65,536^2, every LDS read feeds two MFMAs.  Logsumexp
+// epilogues only; kernel sums, permutation sums and the split-bf16 contraction keep one column block at this width.
+static int launch_64x2(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
+                       float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
+                       bool excl, int64_t excl_offset, int epi, const int* redo_flags, hipStream_t st) {
+    const dim3 grid((unsigned)(p.cpad / (4 * 32 * 2)), (unsigned)p.nsplit);
+    const PermArgs pa{};
+#define LVAE_PAIR(X, E)                                                                              \
+    hipLaunchKernelGGL((pair_lse_mfma_kernel<64, 2, 2, X, E>), grid, dim3(256), 0, st, rfrag, rbias, \
+                       cop, partial, hdr, cond_limit, use_if_above, p.nblk, p.blk_per_split, p.cpad,  \
+                       excl_offset, pa, redo_flags, 0, nullptr)
+    // (with the diagonal excluded the masked copies of the biases need 32 more registers and spill: those calls keep
+    //  one column block, lvae_log_qz_plan)
+    if (excl) return lvae_set_error(LVAE_ERR_INVALID, "two column blocks at D = 64: not with an excluded diagonal");
+    if (epi == 0) LVAE_PAIR(false, 0);
+    else if (epi == 4) LVAE_PAIR(false, 4);
+    else return lvae_set_error(LVAE_ERR_INVALID, "two column blocks at D = 64 serve the logsumexp epilogues only (epi %d)", epi);
+#undef LVAE_PAIR
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
 int lvae_launch_pair_mfma(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                           float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
                           bool excl, int64_t excl_offset, int epi, const int* redo_flags, int sym, const float* colnorm,
@@ -53,7 +76,9 @@ int lvae_launch_pair_mfma(const PairPlan& p, const float* rfrag, const float* rb
     switch (p.DP) {
         case 16: return launch_t<16, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, colnorm, st);
         case 32: return launch_t<32, 2, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, colnorm, st);
-        case 64: return launch_t<64, 1, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, colnorm, st);
+        case 64:
+            if (p.NCB == 2) return launch_64x2(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, st);
+            return launch_t<64, 1, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, colnorm, st);
         case 128: return launch_t<128, 1, 1>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, colnorm, st);
         default:
             return lvae_set_error(LVAE_ERR_UNSUPPORTED, "MFMA path needs D <= 128 (got D=%d)", p.D);

@@ -121,7 +121,15 @@ static inline size_t lvae_align256(size_t x) { return (x + 255) & ~(size_t)255; 
 // sym: the MFMA grid only does work on the upper triangle of tiles, uneven per workgroup -> cut the reduced
 // axis finer so that the hardware dispatcher can balance it.
 static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool with_pm, int force_ncb = 0,
-                                           bool sym = false) {
+                                           bool sym = false);
+
+// The plan of log q(z) (samples kept, posteriors reduced): at D in (32, 64] the fp32 contraction runs two column
+// blocks per wave (pair_lse_mfma.hip: launch_64x2), the split-bf16 contraction (bx) one.
+static inline PairPlan lvae_log_qz_plan(int64_t N, int64_t M, int D, bool with_pm, bool bx, bool excl = false) {
+    return lvae_make_pair_plan(N, M, D, with_pm, (!bx && !excl && lvae_pad_dim(D) == 64) ? 2 : 0, false);
+}
+
+static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool with_pm, int force_ncb, bool sym) {
     PairPlan p{};
     p.R = R; p.C = C; p.D = D; p.with_pm = with_pm;
     p.DP = lvae_pad_dim(D);
