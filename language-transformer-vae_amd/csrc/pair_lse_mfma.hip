@@ -64,6 +64,24 @@ static int launch_64x2(const PairPlan& p, const float* rfrag, const float* rbias
     return LVAE_OK;
 }
 
+// D in (64, 128], logsumexp epilogues: two workgroups per CU (202-228 registers, no spills; the kernel-sum epilogues
+// need up to 268 and stay at one).  65,536^2 at D = 128: 90.9 -> 91.6 % of peak; the plans of log q(z) count 512 slots.
+static int launch_128w2(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
+                        float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
+                        bool excl, int64_t excl_offset, int epi, const int* redo_flags, hipStream_t st) {
+    const dim3 grid((unsigned)(p.cpad / (4 * 32)), (unsigned)p.nsplit);
+    const PermArgs pa{};
+#define LVAE_PAIR(X, E)                                                                               \
+    hipLaunchKernelGGL((pair_lse_mfma_kernel<128, 1, 2, X, E>), grid, dim3(256), 0, st, rfrag, rbias, \
+                       cop, partial, hdr, cond_limit, use_if_above, p.nblk, p.blk_per_split, p.cpad,   \
+                       excl_offset, pa, redo_flags, 0, nullptr)
+    if (epi == 0) { if (excl) LVAE_PAIR(true, 0); else LVAE_PAIR(false, 0); }
+    else { if (excl) LVAE_PAIR(true, 4); else LVAE_PAIR(false, 4); }
+#undef LVAE_PAIR
+    LVAE_LAUNCH_CHECK();
+    return LVAE_OK;
+}
+
 int lvae_launch_pair_mfma(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
                           float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
                           bool excl, int64_t excl_offset, int epi, const int* redo_flags, int sym, const float* colnorm,
@@ -79,7 +97,9 @@ int lvae_launch_pair_mfma(const PairPlan& p, const float* rfrag, const float* rb
         case 64:
             if (p.NCB == 2) return launch_64x2(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, st);
             return launch_t<64, 1, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, colnorm, st);
-        case 128: return launch_t<128, 1, 1>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, colnorm, st);
+        case 128:
+            if ((epi == 0 || epi == 4) && p.NCB == 1) return launch_128w2(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, st);
+            return launch_t<128, 1, 1>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl, excl_offset, epi, redo_flags, sym, colnorm, st);
         default:
             return lvae_set_error(LVAE_ERR_UNSUPPORTED, "MFMA path needs D <= 128 (got D=%d)", p.D);
     }

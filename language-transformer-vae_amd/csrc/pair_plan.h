@@ -121,15 +121,16 @@ static inline size_t lvae_align256(size_t x) { return (x + 255) & ~(size_t)255; 
 // sym: the MFMA grid only does work on the upper triangle of tiles, uneven per workgroup -> cut the reduced
 // axis finer so that the hardware dispatcher can balance it.
 static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool with_pm, int force_ncb = 0,
-                                           bool sym = false);
+                                           bool sym = false, bool lse = false);
 
 // The plan of log q(z) (samples kept, posteriors reduced): at D in (32, 64] the fp32 contraction runs two column
 // blocks per wave (pair_lse_mfma.hip: launch_64x2), the split-bf16 contraction (bx) one.
 static inline PairPlan lvae_log_qz_plan(int64_t N, int64_t M, int D, bool with_pm, bool bx, bool excl = false) {
-    return lvae_make_pair_plan(N, M, D, with_pm, (!bx && !excl && lvae_pad_dim(D) == 64) ? 2 : 0, false);
+    return lvae_make_pair_plan(N, M, D, with_pm, (!bx && !excl && lvae_pad_dim(D) == 64) ? 2 : 0, false, true);
 }
 
-static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool with_pm, int force_ncb, bool sym) {
+// lse: the plan is for a logsumexp epilogue (two workgroups per CU at every width; kernel sums at D > 128: one)
+static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool with_pm, int force_ncb, bool sym, bool lse) {
     PairPlan p{};
     p.R = R; p.C = C; p.D = D; p.with_pm = with_pm;
     p.DP = lvae_pad_dim(D);
@@ -139,13 +140,13 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
     const int64_t wg_cols = p.DP ? 4 * 32 * p.NCB : 256;
     p.cpad = lvae_round_up(C, wg_cols < 256 ? 256 : wg_cols);
     // MFMA grid: (column groups) x (reduced-axis splits).  All workgroups of a launch do the same work, S of
-    // them are resident at a time (two per CU, one for the D=128 variant), so the time is
+    // them are resident at a time (two per CU; one for the kernel-sum epilogues at D > 128), so the time is
     // rounds * (blocks per split + per-workgroup overhead) with rounds = ceil(groups * splits / S): pick the
     // split count that minimises it (a grid of 543 equal workgroups on 512 slots would take two full rounds).
     // At least five rounds' worth of workgroups (sym: uneven work per workgroup -> eight) when the axis allows.
     const int64_t groups = p.DP ? p.cpad / (4 * 32 * p.NCB) : 1;
     const char* tw_env = getenv("LVAE_NSPLIT");
-    const int64_t slots = 256 * (p.DP == 128 ? 1 : 2);
+    const int64_t slots = 256 * ((p.DP == 128 && !lse) ? 1 : 2);
     const int64_t max_ns = p.nblk < 64 ? (p.nblk < 1 ? 1 : p.nblk) : 64;
     int64_t ns = 1;
     if (tw_env) {
