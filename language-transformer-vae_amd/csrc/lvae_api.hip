@@ -853,7 +853,7 @@ extern "C" int lvae_qz_estimate_f32(const float* z, const float* mu, const float
     if (rc) return rc;
     LVAE_CHECK_ARG(out, "out is NULL");
     hipStream_t st = (hipStream_t)stream;
-    const PairPlan p = lvae_make_pair_plan(M, N, D, false);
+    const PairPlan p = lvae_make_pair_plan(M, N, D, false, 0, false, true);
     rc = check_ws(ws, ws_bytes, p.total);
     if (rc) return rc;
     if (p.DP == 0)
@@ -980,7 +980,7 @@ static size_t bounds_tail_bytes(int64_t K) { return lvae_align256((size_t)K * 3 
 extern "C" int lvae_pair_bounds_workspace_bytes(int64_t K, int D, int64_t* out_bytes) {
     LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
     LVAE_CHECK_ARG(K >= 2 && D >= 1 && D <= 4096, "need K >= 2 and 1 <= D <= 4096");
-    const PairPlan p = lvae_make_pair_plan(K, K, D, false);
+    const PairPlan p = lvae_make_pair_plan(K, K, D, false, 0, false, true);
     *out_bytes = (int64_t)(p.total + bounds_tail_bytes(K));
     return LVAE_OK;
 }
@@ -992,7 +992,7 @@ extern "C" int lvae_pair_bounds_f32(const float* z, const float* mu, const float
     int rc = check_pair_shapes(z, mu, var, LVAE_SPREAD_VAR, K, K, D);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const PairPlan p = lvae_make_pair_plan(K, K, D, false);
+    const PairPlan p = lvae_make_pair_plan(K, K, D, false, 0, false, true);
     rc = check_ws(ws, ws_bytes, p.total + bounds_tail_bytes(K));
     if (rc) return rc;
     float* tail = (float*)((char*)ws + p.total);

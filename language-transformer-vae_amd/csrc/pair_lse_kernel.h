@@ -143,7 +143,12 @@ pair_lse_body(const float* __restrict__ rfrag, const float* __restrict__ rbias,
         ks[cb] = 0.0;
     }
 
-    int64_t b0 = (int64_t)blockIdx.y * blk_per_split;
+    // sym: the splits are walked from the LAST row range to the first.  Work per workgroup grows with the row range
+    // (a column block only visits rows from its diagonal on), and the hardware dispatches in blockIdx order: the
+    // fullest workgroups must go first, the empty ones last, or the launch ends on a tail of full workgroups.
+    const int64_t ysplit = (KS && sym != 0) ? (nblk + blk_per_split - 1) / blk_per_split - 1 - (int64_t)blockIdx.y
+                                            : (int64_t)blockIdx.y;
+    int64_t b0 = ysplit * blk_per_split;
     int64_t b1 = b0 + blk_per_split;
     if (b1 > nblk) b1 = nblk;
     // sym (kernel sums of a sample against itself, totals only): the matrix is symmetric, so a column
@@ -658,7 +663,7 @@ pair_lse_body(const float* __restrict__ rfrag, const float* __restrict__ rbias,
         for (int cb = 0; cb < NCB; ++cb) {
             const float sv = kt2[cb].x + kt2[cb].y;
             const float ss = sv + __shfl_xor(sv, 32, 64);
-            if (h == 0) partial[(int64_t)blockIdx.y * cpad + col0 + cb * 32 + r] = make_float2(0.f, ss);
+            if (h == 0) partial[ysplit * cpad + col0 + cb * 32 + r] = make_float2(0.f, ss);
         }
         return;
     }
@@ -667,11 +672,11 @@ pair_lse_body(const float* __restrict__ rfrag, const float* __restrict__ rbias,
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             const double tot = ks[cb] + __shfl_xor(ks[cb], 32, 64);
-            if (h == 0) kpartial[(int64_t)blockIdx.y * cpad + col0 + cb * 32 + r] = tot;
+            if (h == 0) kpartial[ysplit * cpad + col0 + cb * 32 + r] = tot;
         }
         if (PERM) {
             const double dtot = ksd + __shfl_xor(ksd, 32, 64);
-            if (h == 0) pa.diag_partial[(int64_t)blockIdx.y * cpad + col0 + r] = dtot;
+            if (h == 0) pa.diag_partial[ysplit * cpad + col0 + r] = dtot;
         }
         return;
     }
@@ -681,7 +686,7 @@ pair_lse_body(const float* __restrict__ rfrag, const float* __restrict__ rbias,
         const float so = __shfl_xor(s[cb], 32, 64);
         const float mm = fmaxf(m[cb], mo);
         const float ss = s[cb] * lvae_exp2(m[cb] - mm) + so * lvae_exp2(mo - mm);
-        if (h == 0) partial[(int64_t)blockIdx.y * cpad + col0 + cb * 32 + r] = make_float2(mm, ss);
+        if (h == 0) partial[ysplit * cpad + col0 + cb * 32 + r] = make_float2(mm, ss);
     }
 }
 

@@ -182,6 +182,14 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
                 ns_model = c;
             }
         }
+        // (3) Kernel sums below the many-rounds regime (measured on the three-job MMD launch, tools/sweep_mmd_nsplit.py,
+        //     n = 2,048 ... 32,768): their tiles carry twice the vector work and the symmetric jobs' workgroups are
+        //     uneven, so fine splits pack better than the model above says -- down to four blocks per split, at most 32
+        //     splits (16,384: 598 -> 542 us, 8,192: 215 -> 198, 4,096: 96 -> 80).
+        if (!lse) {
+            ns_model = p.nblk / 4 < 1 ? 1 : p.nblk / 4;
+            if (ns_model > 32) ns_model = 32;
+        }
         ns = lvae_ceil_div(p.nblk, ns_rounds) >= 128 ? ns_rounds : ns_model;
     }
     if (ns > max_ns) ns = max_ns;
