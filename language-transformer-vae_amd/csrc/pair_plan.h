@@ -190,6 +190,21 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
             ns_model = p.nblk / 4 < 1 ? 1 : p.nblk / 4;
             if (ns_model > 32) ns_model = 32;
         }
+        // (4) Logsumexp plans from ~12,000 reduced rows up to the many-rounds regime: sixteen splits at least.  One
+        //     round of few large workgroups (when that is what the model above picks) loses to 1.5-3 rounds of smaller ones --
+        //     measured, tools/sweep_nsplit.py, D = 32, pair kernel: 12,288^2 177 -> 155 us, 24,576^2 624 -> 578,
+        //     32,768^2 1,035 -> 1,017, 16,384^2 unchanged (267 / 265).
+        if (lse && p.nblk >= 384 && ns_model < 16 && groups * ns_model <= slots) {
+            best = 1e300;
+            for (int64_t c = 16; c <= max_ns; ++c) {       // the same model, from sixteen splits on
+                const double bps = (double)lvae_ceil_div(p.nblk, c);
+                const double cost = (double)lvae_ceil_div(groups * c, slots) * (bps + 4.0);
+                if (cost < best * 0.97) {
+                    best = cost;
+                    ns_model = c;
+                }
+            }
+        }
         ns = lvae_ceil_div(p.nblk, ns_rounds) >= 128 ? ns_rounds : ns_model;
     }
     if (ns > max_ns) ns = max_ns;
