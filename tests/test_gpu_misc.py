@@ -60,10 +60,11 @@ def test_mi_bounds(case):
     assert lower <= np.log(len(g["z"])) + 1e-5      # InfoNCE <= log K (float32 rounding slack)
 
 
-def test_mi_bounds_large_vs_oracle():
+@pytest.mark.parametrize("K,D", [(1500, 32), (700, 16), (900, 64), (600, 100), (500, 128)])
+def test_mi_bounds_large_vs_oracle(K, D):
+    """(every width of the pair kernel with the diagonal excluded: D = 16 / 32 / 64 / 128 variants)"""
     from lvae import mutual_information as MI
     rng = np.random.default_rng(3)
-    K, D = 1500, 32
     mu = rng.standard_normal((K, D)).astype(np.float32)
     lv = (0.5 * rng.standard_normal((K, D)) - 1).astype(np.float32)
     z = (mu + rng.standard_normal((K, D)).astype(np.float32) * np.exp(0.25 * lv)).astype(np.float32)
