@@ -282,6 +282,57 @@ class Bench:
                 "k_avg_ms": k_avg_ms, "achieved": achieved,
                 "pct_of_peak": value * 4 * D / (self.world * FP32_MFMA_PEAK_TFLOPS * 1e12) * 100.0}
 
+    def other_configs(self):
+        """BASELINE configs[3] and configs[4] on this GPU, timed after the headline measurement and nested in the same
+        line (side records: the headline `value` never depends on them; an error is recorded as text)."""
+        torch = self.torch
+        from lvae import estimators as E
+        out = {}
+
+        def timed(fn, reps):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                r = fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps, r
+
+        try:        # configs[4]: IW reduction, K = 1,000 samples x 16,384 sentences, D = 32 (HBM-bound)
+            B, K, D = 16384, 1000, 32
+            g = torch.Generator(device=self.device).manual_seed(7)
+            mu = torch.randn(B, D, device=self.device, generator=g)
+            lv = 0.5 * torch.randn(B, D, device=self.device, generator=g) - 1.0
+            eps = torch.randn(B, K, D, device=self.device, generator=g)
+            lpxz = 5.0 * torch.randn(B, K, device=self.device, generator=g) - 100.0
+            t_red, r = timed(lambda: E.reparam_iw(mu, lv, eps, lpxz, return_z=False, return_densities=False), 20)
+            t_den, _ = timed(lambda: E.reparam_iw(mu, lv, eps, lpxz, return_z=False), 20)
+            by = B * K * (4 * D + 4)
+            out["configs4_iw"] = {"B": B, "K": K, "D": D, "ms_reduction_only": t_red * 1e3, "GBps_reduction_only": by / t_red / 1e9,
+                                  "frac_of_8TBps": by / t_red / 8e12, "ms_with_density_matrices": t_den * 1e3,
+                                  "unit_rate": B * K / t_red, "unit": "(sentence, sample)/s",
+                                  "iw_ll_mean": float(r["iw_ll"].double().mean())}
+            del eps, lpxz, r
+        except Exception as e:
+            out["configs4_iw"] = {"error": repr(e)}
+        try:        # configs[3]: MMD permutation test, n1 = n2 = 262,144, D = 32, 100 permutations (one GPU)
+            n, D, P = 262144, 32, 100
+            g = torch.Generator(device=self.device).manual_seed(11)
+            x = torch.randn(n, D, device=self.device, generator=g)
+            y = 0.98 * torch.randn(n, D, device=self.device, generator=g) + 0.01
+            alphas = [0.1 * i for i in range(15)]
+            labels = E.permutation_labels(n, n, P, self.device, g)
+            t_perm, r = timed(lambda: E.mmd_permutation_test(x, y, alphas, labels=labels), 2)
+            t_stat, _ = timed(lambda: E.mmd_rbf(x, y, alphas, 1e-5, unbiased=True), 2)
+            nn = 2.0 * n
+            out["configs3_mmd_perm"] = {"n1": n, "n2": n, "D": D, "permutations": P, "ms": t_perm * 1e3,
+                                        "ms_statistic_alone": t_stat * 1e3, "pooled_entries_per_s": nn * nn / t_perm,
+                                        "statistic": float(r["statistic"]), "pval": float(r["pval"]),
+                                        "note": "parity unpinned (torch-two-sample absent); fp32 mode"}
+        except Exception as e:
+            out["configs3_mmd_perm"] = {"error": repr(e)}
+        return out
+
     def run(self):
         args, world, rank, torch = self.args, self.world, self.rank, self.torch
         D = args.d
@@ -379,6 +430,8 @@ class Bench:
                     "note": "opt-in path, not the north star's fp32 MFMA contraction; see DESIGN.md"}
             except Exception as e:                       # never lose the headline line over the side measurement
                 line["experimental_bf16x3"] = {"error": repr(e)}
+            if not args.no_side_runs and D == 32:
+                line["also_measured"].update(self.other_configs())
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(torch, mu, logvar, z, log_norm, m["out"]["log_q_z_local"], D)
         if rank == 0:
