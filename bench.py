@@ -109,7 +109,7 @@ def resolve_workload(args, world):
     if name == "c2":
         if world != 1:
             raise SystemExit("workload c2 is the single-GPU configuration; use 1m or weak with --gpus > 1")
-        return name, BASE_N, "weak", ("BASELINE configs[1]: aggregate-posterior log q(z) matrix + logsumexp -> "
+        return name, BASE_N, "none", ("BASELINE configs[1]: aggregate-posterior log q(z) matrix + logsumexp -> "
                                       "marginal KL / MI, fused fp32 MFMA")
     if name == "1m":
         tag = "BASELINE configs[2]" if args.d == 64 else "north star 'scaling to 8 GPUs at N=1M' (configs[2] shape at the metric's D)"

@@ -44,10 +44,17 @@ typedef enum {
                                 * the bf16 matrix pipe (three limbs per value, fp32-equivalent), else on the VALU */
 #define LVAE_PATH_MFMA 1       /* fp32 MFMA quadratic expansion                */
 #define LVAE_PATH_DIRECT 2     /* VALU direct form (z-mu)^2 p, no cancellation */
-#define LVAE_PATH_MFMA_BF16X3 3 /* EXPERIMENTAL, opt-in: the same expansion as three bf16 limbs per value (six
-                                * limb products, fp32 accumulate, fp32-equivalent accuracy); D <= 64 (with
-                                * prod-marginals: their polynomial too, ungated); the joint-density form is
-                                * never chosen by LVAE_PATH_AUTO */
+#define LVAE_PATH_MFMA_BF16X3 3 /* the same expansion as three bf16 limbs per value (six limb products, fp32
+                                * accumulate, fp32-equivalent accuracy); D <= 64 (with prod-marginals: their
+                                * polynomial too, ungated).  For the log-density matrix (lvae_log_qz_f32 and
+                                * friends) it is opt-in: the north star asks for the fp32 MFMA contraction there
+                                * and LVAE_PATH_AUTO never picks this form.  The kernel sums of the MMD entry points
+                                * (lvae_mmd_rbf_f32, lvae_kernel_sum_f32, lvae_mmd_perm_f32; D <= 128) take it under
+                                * LVAE_PATH_AUTO from 2^27 pairs on, behind a device-side gate on the largest squared
+                                * norm of the points (alpha_max * 4 max|p|^2 <= 2e4; beyond it the fp32 MFMA kernel
+                                * runs): 1.55-1.7x the fp32 rate.  For those entry points LVAE_PATH_MFMA is the fp32
+                                * contraction, LVAE_PATH_DIRECT exact differences on the vector ALU (any D; the only
+                                * form at D > 256; not for the permutation sums). */
 
 const char* lvae_last_error(void);
 int lvae_version(void);
@@ -75,8 +82,10 @@ int lvae_log_qz_f32(const float* z, const float* mu, const float* spread, int sp
  * library, LVAE_NOALLOC_SCRATCH_BYTES (64 MiB) on every GPU the library runs on, held until the process ends;
  * shapes whose plan needs more (lvae_log_qz_workspace_bytes) are rejected with LVAE_ERR_UNSUPPORTED -- e.g.
  * M = N = 4,096 with prod-marginals or M = N = 32,768 without fit at D = 32.  The call issues no hipMalloc /
- * hipFree (its first call on a device looks the array's address up once).  All calls on one GPU share that GPU's
- * array: calls that overlap on one GPU (two streams, two threads) race; serialise them. */
+ * hipFree.  Its FIRST call on a device looks the array's address up once (hipGetSymbolAddress) and makes the runtime
+ * load the kernels: under HIP graph capture make one ordinary, un-captured warm-up call per device first, then capture.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race;
+ * serialise them. */
 #define LVAE_NOALLOC_SCRATCH_BYTES (64u << 20)
 int lvae_log_qz_noalloc_f32(const float* z, const float* mu, const float* spread, int spread_kind,
                             int64_t M, int64_t N, int D, float log_norm,
@@ -299,11 +308,12 @@ int lvae_kde_score_f32(const float* X, const float* Y, int64_t n, int64_t n_norm
  * x [n1,D], y [n2,D] device; alphas: HOST array of n_alpha >= 1 non-negative floats (n_alpha <= 32).
  * D <= 256: the cross term -2 x.y on the matrix cores (two dimensions per MFMA step, the squared norms enter
  * as biases); 256 < D <= 4096 (wide latents at training-time batch sizes): direct differences on the vector
- * ALU, O(n1 n2 D).
+ * ALU, O(n1 n2 D).  `path`: LVAE_PATH_AUTO / _MFMA / _DIRECT / _MFMA_BF16X3 as described at their definitions
+ * (per call: there is no process-wide mode).
  * out: 4 float64 in device memory = {statistic, sum Kxx, sum Kyy, sum Kxy}. */
 int lvae_mmd_workspace_bytes(int64_t n1, int64_t n2, int D, int64_t* out_bytes);
 int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int64_t n2, int D, const float* alphas,
-                     int n_alpha, float dist_eps, int unbiased, double* out, void* ws, int64_t ws_bytes,
+                     int n_alpha, float dist_eps, int unbiased, int path, double* out, void* ws, int64_t ws_bytes,
                      void* stream);
 
 /* One block of the kernel-matrix sums above: sum over i < na, j < nb of k(a_i, b_j), same kernel k as
@@ -316,7 +326,7 @@ int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int64_t n2, int
  * still add up to the sum over the full symmetric matrix (out_colsum must be NULL). */
 int lvae_kernel_sum_workspace_bytes(int64_t na, int64_t nb, int D, int64_t* out_bytes);
 int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, int64_t nb, int D, const float* alphas,
-                        int n_alpha, float dist_eps, int exclude_diag, int64_t diag_offset, int symmetric,
+                        int n_alpha, float dist_eps, int exclude_diag, int64_t diag_offset, int symmetric, int path,
                         double* out_total, double* out_colsum, void* ws, int64_t ws_bytes, void* stream);
 
 /* Label-permutation sums for the MMD permutation test (torch_two_sample MMDStatistic.pval; the C4
@@ -342,7 +352,7 @@ int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, int64_t nb, 
 int lvae_mmd_perm_workspace_bytes(int64_t nc, int64_t n, int D, int64_t* out_bytes);
 int lvae_mmd_perm_f32(const float* cols, int64_t nc, int64_t col_offset, const float* pooled, int64_t n, int D,
                       const unsigned char* labels, int P, const float* alphas, int n_alpha, float dist_eps,
-                      int symmetric, double* out, void* ws, int64_t ws_bytes, void* stream);
+                      int symmetric, int path, double* out, void* ws, int64_t ws_bytes, void* stream);
 
 /* The kernel matrix itself (gaussian_kernel, loss_and_optimisation.py:63-76; MMDStatistic ret_matrix):
  * out[i, j] = k(x_i, y_j), out [n1, n2]; alphas on the HOST as above.  Workspace: LVAE_KMAT_WS_BYTES. */
@@ -371,17 +381,6 @@ int lvae_ks_2samp_workspace_bytes(int64_t n1, int64_t n2, int64_t* out_bytes);
 int lvae_ks_2samp_f32(const float* a, int64_t n1, const float* b, int64_t n2, double* out, void* ws,
                       int64_t ws_bytes, void* stream);
 
-/* EXPERIMENTAL, opt-in, process-wide (no counterpart in the reference): the contraction behind the entry
- * points that have no `path` argument (lvae_mmd_rbf_f32, lvae_kernel_sum_f32, lvae_mmd_perm_f32).
- * LVAE_MATH_FP32 (default): fp32 MFMA.  LVAE_MATH_BF16X3: three bf16 limbs per fp32 value, six limb products on
- * the bf16 matrix pipe, fp32 accumulate (fp32-equivalent results) wherever the kernel supports it (D <= 64;
- * wider latents silently stay on fp32; the kernel sums contract D / 2 steps, so D <= 128 there).  Read when a
- * call is issued; not meant to be flipped while calls of other threads are being issued. */
-#define LVAE_MATH_FP32 0
-#define LVAE_MATH_BF16X3 1
-int lvae_set_pair_math(int mode);
-int lvae_get_pair_math(void);
-
 /* ---------------------------------------------------------------------------------------------
  * Measurement aid (no counterpart in the reference): HIP events recorded on the caller's stream
  * around the pair kernels of lvae_log_qz_f32 / lvae_log_qz_partial_f32, so a benchmark can time the
@@ -389,6 +388,11 @@ int lvae_get_pair_math(void);
  * ------------------------------------------------------------------------------------------- */
 int lvae_profile_begin(int max_launches);
 int lvae_profile_end(double* total_ms, int* launches);
+
+/* Development aid (no counterpart in the reference): the library reads its LVAE_* environment switches (DESIGN.md
+ * section 8: forced split counts, path thresholds, ...) once per process; a sweep or a test that changes one inside a
+ * running process calls this to have them read again.  Not for use while other threads are inside the library. */
+int lvae_dev_reload_env(void);
 
 #ifdef __cplusplus
 }

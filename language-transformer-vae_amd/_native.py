@@ -13,8 +13,7 @@ LIB_PATH = os.environ.get("LVAE_LIB", os.path.join(_HERE, "liblvae.so"))
 
 SPREAD_LOGVAR, SPREAD_VAR = 0, 1
 PATH_AUTO, PATH_MFMA, PATH_DIRECT = 0, 1, 2
-PATH_MFMA_BF16X3 = 3      # experimental, opt-in (include/lvae.h)
-MATH_FP32, MATH_BF16X3 = 0, 1
+PATH_MFMA_BF16X3 = 3      # split-bf16 contraction (include/lvae.h): opt-in for log q(z), AUTO's choice for large kernel sums
 
 _lib = None
 
@@ -65,8 +64,6 @@ _SIGNATURES = {
     "lvae_lse_combine_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _f32, _c_f32p, _c_f32p, _c_f32p,
                                     ctypes.c_void_p]),
     "lvae_lse_rebase_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, ctypes.c_void_p]),
-    "lvae_set_pair_math": (_int, [_int]),
-    "lvae_get_pair_math": (_int, []),
     "lvae_log_prob_pairs_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _int, _i64, _i64, _int, _c_f32p,
                                        ctypes.c_void_p]),
     "lvae_gauss_ll_masked_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _int, ctypes.POINTER(_i64),
@@ -79,11 +76,11 @@ _SIGNATURES = {
     "lvae_kde_score_f32": (_int, [_c_f32p, _c_f32p, _i64, _i64, _i64, _int, _f32, _int, _c_f32p, ctypes.c_void_p, _i64,
                                   ctypes.c_void_p]),
     "lvae_mmd_workspace_bytes": (_int, [_i64, _i64, _int, ctypes.POINTER(_i64)]),
-    "lvae_mmd_rbf_f32": (_int, [_c_f32p, _c_f32p, _i64, _i64, _int, ctypes.POINTER(_f32), _int, _f32, _int,
+    "lvae_mmd_rbf_f32": (_int, [_c_f32p, _c_f32p, _i64, _i64, _int, ctypes.POINTER(_f32), _int, _f32, _int, _int,
                                 ctypes.c_void_p, ctypes.c_void_p, _i64, ctypes.c_void_p]),
     "lvae_kernel_sum_workspace_bytes": (_int, [_i64, _i64, _int, ctypes.POINTER(_i64)]),
     "lvae_kernel_sum_f32": (_int, [_c_f32p, _c_f32p, _i64, _i64, _int, ctypes.POINTER(_f32), _int, _f32, _int,
-                                   _i64, _int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _i64,
+                                   _i64, _int, _int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _i64,
                                    ctypes.c_void_p]),
     "lvae_log_qz_bwd_workspace_bytes": (_int, [_i64, _i64, _int, _int, ctypes.POINTER(_i64)]),
     "lvae_log_qz_bwd_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _i64, _int, _f32, _c_f32p, _c_f32p, _c_f32p,
@@ -98,12 +95,13 @@ _SIGNATURES = {
     "lvae_layout_info": (_int, [_int, _i64, _i64, _int, _int, ctypes.POINTER(_i64)]),
     "lvae_mmd_perm_workspace_bytes": (_int, [_i64, _i64, _int, ctypes.POINTER(_i64)]),
     "lvae_mmd_perm_f32": (_int, [_c_f32p, _i64, _i64, _c_f32p, _i64, _int, ctypes.c_void_p, _int,
-                                 ctypes.POINTER(_f32), _int, _f32, _int, ctypes.c_void_p, ctypes.c_void_p, _i64,
+                                 ctypes.POINTER(_f32), _int, _f32, _int, _int, ctypes.c_void_p, ctypes.c_void_p, _i64,
                                  ctypes.c_void_p]),
     "lvae_kernel_matrix_f32": (_int, [_c_f32p, _c_f32p, _i64, _i64, _int, ctypes.POINTER(_f32), _int, _f32,
                                       _c_f32p, ctypes.c_void_p, _i64, ctypes.c_void_p]),
     "lvae_profile_begin": (_int, [_int]),
     "lvae_profile_end": (_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_int)]),
+    "lvae_dev_reload_env": (_int, []),
 }
 
 NOALLOC_SCRATCH_BYTES = 64 << 20
@@ -205,27 +203,7 @@ def host_floats(values):
     return arr, len(values)
 
 
-def set_pair_math(mode):
-    """Process-wide contraction of the kernel-sum / MMD entry points: MATH_FP32 (default) or MATH_BF16X3
-    (experimental, include/lvae.h)."""
-    check(lib().lvae_set_pair_math(int(mode)))
-
-
-def get_pair_math():
-    return lib().lvae_get_pair_math()
-
-
-class pair_math:
-    """``with pair_math(MATH_BF16X3): ...`` -- set the mode for a block and restore the previous one."""
-
-    def __init__(self, mode):
-        self.mode = mode
-
-    def __enter__(self):
-        self.old = get_pair_math()
-        set_pair_math(self.mode)
-        return self
-
-    def __exit__(self, *exc):
-        set_pair_math(self.old)
-        return False
+def reload_env():
+    """Have the library read its LVAE_* environment switches again (they are read once per process); for sweeps and
+    tests that change one inside a running process."""
+    check(lib().lvae_dev_reload_env())

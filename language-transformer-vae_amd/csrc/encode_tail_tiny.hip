@@ -335,19 +335,23 @@ static TinyGeom tiny_geom(int64_t B, int64_t K, int D, float log_norm) {
     return G;
 }
 
-static int tiny_allow_lds() {      // dynamic LDS above 64 KB needs the attribute, once per process and kernel
-    static std::once_flag once;
-    static hipError_t err = hipSuccess;
-    std::call_once(once, [] {
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(encode_tail_tiny_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-        if (err == hipSuccess)
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(encode_tail_tiny_bwd_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    if (err != hipSuccess)
-        return lvae_set_error(LVAE_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s",
-                              hipGetErrorString(err));
+// dynamic LDS above 64 KB needs the attribute; it belongs to the DEVICE that is current when it is set, so it is
+// set once per device ordinal (a process that drives several GPUs launches on each of them)
+#define TINY_MAX_DEVICES 64
+static int tiny_allow_lds() {
+    static std::mutex mu;
+    static bool done[TINY_MAX_DEVICES];
+    int dev = -1;
+    LVAE_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= TINY_MAX_DEVICES)
+        return lvae_set_error(LVAE_ERR_UNSUPPORTED, "device ordinal %d outside 0..%d", dev, TINY_MAX_DEVICES - 1);
+    std::lock_guard<std::mutex> lk(mu);
+    if (done[dev]) return LVAE_OK;
+    LVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(encode_tail_tiny_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    LVAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(encode_tail_tiny_bwd_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done[dev] = true;
     return LVAE_OK;
 }
 

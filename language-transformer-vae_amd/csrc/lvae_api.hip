@@ -91,8 +91,9 @@ int lvae_launch_ksum_columns(const double* partial, int nsplit, int64_t cpad, in
                              int64_t excl_offset, int zero_alphas, double* colsum, double* total,
                              hipStream_t st);
 int lvae_launch_pair_mfma_perm(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
-                               float2* partial, const PairHeader* hdr, int64_t excl_offset, int epi,
-                               const PermArgs& pa, int sym, const float* colnorm, hipStream_t st);
+                               float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
+                               int64_t excl_offset, int epi, const PermArgs& pa, int sym, const float* colnorm,
+                               hipStream_t st);
 int lvae_launch_prep_labels(const unsigned char* labels, int P, int64_t n, int64_t nblk, void* out,
                             hipStream_t st);
 int lvae_launch_perm_lr(const double* partial, const double* diag_partial, int nsplit, int64_t cpad, int64_t C,
@@ -143,8 +144,9 @@ int lvae_launch_ks_2samp(const float* a, int64_t n1, const float* b, int64_t n2,
                          hipStream_t st);
 bool lvae_bf16x3_supported(int DP);
 int lvae_launch_pair_bf16x3_perm(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
-                                 float2* partial, const PairHeader* hdr, int64_t excl_offset, int epi,
-                                 const PermArgs& pa, int sym, const float* colnorm, hipStream_t st);
+                                 float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
+                                 int64_t excl_offset, int epi, const PermArgs& pa, int sym, const float* colnorm,
+                                 hipStream_t st);
 int lvae_launch_prep_bf16x3(int src, bool frag, const float* x, const float* spread, int spread_kind,
                             int64_t n, int64_t npad, int D, int DP, const PairHeader* hdr, int64_t ngauss,
                             void* out, hipStream_t st);
@@ -183,6 +185,46 @@ int lvae_set_error(int status, const char* fmt, ...) {
 }
 
 extern "C" const char* lvae_last_error(void) { return g_err; }
+
+// ---- development switches: the environment is read once (std::call_once), never on a product call --------------
+#include <mutex>
+static LvaeSwitches g_switches;
+static std::once_flag g_switches_once;
+static void load_switches() {
+    auto num = [](const char* name, long long unset) -> long long {
+        const char* v = getenv(name);
+        return v ? atoll(v) : unset;
+    };
+    LvaeSwitches s{};
+    s.nsplit = num("LVAE_NSPLIT", 0);
+    s.dsplit = num("LVAE_DSPLIT", 0);
+    s.small_pairs = getenv("LVAE_SMALL_PAIRS") ? atof(getenv("LVAE_SMALL_PAIRS")) : -1.0;
+    s.no_small_path = getenv("LVAE_NO_SMALL_PATH") != nullptr;
+    s.prep_rb = getenv("LVAE_PREP_RB") ? (int)num("LVAE_PREP_RB", 0) : 0;
+    if (getenv("LVAE_PREP_RB") && s.prep_rb <= 0) s.prep_rb = -1;      // set but not a count: separate launches, built-in blocks
+    s.no_fused_tail = getenv("LVAE_NO_FUSED_TAIL") != nullptr;
+    s.no_fused_mmd = getenv("LVAE_NO_FUSED_MMD") != nullptr;
+    const char* bp = getenv("LVAE_BWD_PATH");
+    s.bwd_path = !bp ? 0 : (!strcmp(bp, "valu") ? 1 : (!strcmp(bp, "mfma") ? 2 : 0));
+    s.iw_pipe = getenv("LVAE_IW_PIPE") ? (num("LVAE_IW_PIPE", 0) != 0 ? 1 : 0) : -1;
+    s.iw_u = (int)num("LVAE_IW_U", 0);
+    s.iw_tpb = (int)num("LVAE_IW_TPB", 0);
+    s.iw_no_stage = getenv("LVAE_IW_NO_STAGE") != nullptr;
+    s.iw_batch = (int)num("LVAE_IW_BATCH", 0);
+    s.mmd_bx_min_pairs = num("LVAE_MMD_BX_MIN_PAIRS", -1);
+    g_switches = s;
+}
+const LvaeSwitches& lvae_switches() {
+    std::call_once(g_switches_once, load_switches);
+    return g_switches;
+}
+// Re-reads the environment (sweep tools and tests that change a switch inside one process); not for use while other
+// threads are inside the library.
+extern "C" int lvae_dev_reload_env(void) {
+    std::call_once(g_switches_once, load_switches);
+    load_switches();
+    return LVAE_OK;
+}
 extern "C" int lvae_version(void) { return 100; }
 
 // ---- optional per-launch timing of the dominant (pair) kernels ------------------------------------
@@ -190,7 +232,6 @@ extern "C" int lvae_version(void) { return 100; }
 // the dominant kernel alone while timing whole calls.  Off by default; not thread-safe by design
 // (a measurement facility, one measuring thread).
 #include <atomic>
-#include <mutex>
 #include <vector>
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
@@ -354,10 +395,10 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     // ---- small problems: memset, column sums, ONE operand-prep launch, the pair kernel(s) with the running-maximum
     //      epilogue, ONE merge (+ statistics) launch.  Same kernels, same device-side conditioning gate.
     const double pairs = (double)N * (double)M;
-    const char* sp_env = getenv("LVAE_SMALL_PAIRS");      // (threshold sweeps: tools/sweep_small_threshold.py)
-    const double small_pairs = sp_env ? atof(sp_env) : LVAE_SMALL_PAIRS;
+    const LvaeSwitches& sw = lvae_switches();              // (threshold sweeps: tools/sweep_small_threshold.py)
+    const double small_pairs = sw.small_pairs >= 0.0 ? sw.small_pairs : LVAE_SMALL_PAIRS;
     const bool small = p.DP != 0 && !bx && want_joint && pairs <= small_pairs && M <= LVAE_SMALL_MAX_M &&
-                       !(with_pm && pairs >= LVAE_PM_BX_MIN_PAIRS) && !getenv("LVAE_NO_SMALL_PATH");
+                       !(with_pm && pairs >= LVAE_PM_BX_MIN_PAIRS) && !sw.no_small_path;
     if (small) {
         const bool gated_s = joint_path == LVAE_PATH_AUTO;
         const float limit_s = gated_s ? LVAE_COND_LIMIT : -1.0f;
@@ -407,7 +448,7 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
         if (rc) return rc;
         // (gated calls only compare the conditioning estimate with the limit: workgroups below it publish nothing)
         // fp32 contraction: both operands in ONE launch (one 32-row block per workgroup, posterior rows first)
-        const bool prep_both = need_mfma && !bx && !getenv("LVAE_PREP_RB");
+        const bool prep_both = need_mfma && !bx && sw.prep_rb == 0;
         if (prep_both)
             rc = lvae_launch_prep_pair(mu, spread, spread_kind, N, p.nblk * 32, z, M, p.cpad, D, p.DP, hdr, rfrag, rbias,
                                        dparams_now ? dparams : nullptr, p.DC, cop, auto_gate ? LVAE_COND_LIMIT : -1.f, st,
@@ -450,7 +491,7 @@ static int run_log_qz(const float* z, const float* mu, const float* spread, int 
     // (LateMerge): three launches fewer, two of them gates that exit at once on ordinary inputs.
     // Without the statistics (lvae_log_qz_f32) the same kernel runs as the late merge alone: one launch for both merges.
     const bool fuse_tail = log_qz && !row_max && fixed_ref && (tail ? !with_pm : true) && lvae_latent_sums_vec(D) &&
-                           !getenv("LVAE_NO_FUSED_TAIL");
+                           !sw.no_fused_tail;
     int* redo = (int*)(base + p.off_redo);
     const int group_cols = 128 * p.NCB;
     if (need_mfma) {
@@ -729,11 +770,11 @@ extern "C" int lvae_log_qz_bwd_f32(const float* z, const float* mu, const float*
     // mfma: ungated).
     const bool mfma_ok = !pm && lvae_pad_dim(D) != 0;
     const bool valu_ok = D <= 64 || M * N <= LVAE_GRAD_WIDE_MAX_PAIRS;
-    const char* env = getenv("LVAE_BWD_PATH");
+    const int forced = lvae_switches().bwd_path;
     bool use_mfma = mfma_ok;      // (at every size: 50 vs 185 us at 512^2, D = 32; 86 vs 335 us at 2,048^2)
     bool use_valu = !use_mfma || valu_ok;
-    if (env && !strcmp(env, "valu")) { use_mfma = false; use_valu = true; }
-    if (env && !strcmp(env, "mfma") && mfma_ok) { use_mfma = true; use_valu = false; }
+    if (forced == 1) { use_mfma = false; use_valu = true; }
+    if (forced == 2 && mfma_ok) { use_mfma = true; use_valu = false; }
     if (use_valu && !valu_ok)
         return lvae_set_error(LVAE_ERR_UNSUPPORTED,
                               "the backward pass for D > 64 with prod-marginals gradients (or D > 128) keeps an explicit "
@@ -1123,18 +1164,20 @@ static inline int ksum_plan_dim(int D) { return (D + 1) / 2; }
 // Splits the bandwidth list into (count of zeros, KsumParams for the positive ones).  If the positive
 // alphas are all integer multiples (<= LVAE_KSUM_MAX) of the smallest one the sum of exponentials is a
 // polynomial in t = exp(-base*v).
-static int build_ksum(const float* alphas, int n_alpha, float eps, KsumParams* kp, int* zeros) {
+static int build_ksum(const float* alphas, int n_alpha, float eps, KsumParams* kp, int* zeros, float* alpha_max = nullptr) {
     LVAE_CHECK_ARG(alphas, "alphas is NULL");
     LVAE_CHECK_ARG(n_alpha >= 1 && n_alpha <= LVAE_KSUM_MAX, "need 1 <= n_alpha <= %d", LVAE_KSUM_MAX);
     memset(kp, 0, sizeof(*kp));
     kp->eps = eps;
     *zeros = 0;
-    float base = 0.f;
+    float base = 0.f, amax = 0.f;
     for (int k = 0; k < n_alpha; ++k) {
         LVAE_CHECK_ARG(alphas[k] >= 0.f && alphas[k] < 1e30f, "alphas must be finite and non-negative");
         if (alphas[k] == 0.f) ++*zeros;
         else if (base == 0.f || alphas[k] < base) base = alphas[k];
+        if (alphas[k] > amax) amax = alphas[k];
     }
+    if (alpha_max) *alpha_max = amax;
     if (*zeros == n_alpha) {      // nothing but alpha = 0: every pair contributes n_alpha
         kp->poly = 1; kp->n = 0; kp->nbase = 0.f; kp->c[0] = 0.f;
         return LVAE_OK;
@@ -1167,8 +1210,10 @@ static int build_ksum(const float* alphas, int n_alpha, float eps, KsumParams* k
 // Workspace of one kernel-sum pass (kept = a [na], reduced = b [nb]).  The split search of the plan is not
 // monotone in the shape or in `sym`, so every size below is the extent of the plan that will actually be laid
 // out (or the maximum over the plans a call may lay out), never a "largest case" guess.
+static size_t ksum_gate_extra(const PairPlan& p);
 static size_t ksum_pass_extent(int64_t na, int64_t nb, int D, bool sym) {
-    return lvae_make_pair_plan(nb, na, ksum_plan_dim(D), false, 0, sym).total;
+    const PairPlan p = lvae_make_pair_plan(nb, na, ksum_plan_dim(D), false, 0, sym);
+    return p.total + ksum_gate_extra(p);          // (the gated AUTO layout is the largest one of a pass)
 }
 
 // lvae_mmd_rbf_f32 runs three passes in one workspace: (x, x) and (y, y) symmetric, (x, y) plain.
@@ -1238,68 +1283,126 @@ static int ksum_epi(const KsumParams& kp) {
     return paired ? 5 : 2;
 }
 
-// Process-wide choice of the contraction behind the kernel-sum / MMD entry points (which have no `path`
-// argument): 0 = fp32 MFMA (default), 1 = split-bf16 where the kernel supports it (D <= 64).
-static std::atomic<int> g_pair_math{LVAE_MATH_FP32};
-
-extern "C" int lvae_set_pair_math(int mode) {
-    LVAE_CHECK_ARG(mode == LVAE_MATH_FP32 || mode == LVAE_MATH_BF16X3, "unknown pair math mode %d", mode);
-    g_pair_math.store(mode);
+// Contraction of one kernel-sum pass, chosen per call from the entry point's `path` argument:
+//   wide   direct differences on the vector ALU (LVAE_PATH_DIRECT, and every path at D > 256);
+//   bx     the cross term as three bf16 limbs per value on the bf16 matrix pipe (LVAE_PATH_MFMA_BF16X3, ungated);
+//   gated  LVAE_PATH_AUTO on problems of at least LVAE_MMD_BX_MIN_PAIRS pairs: BOTH contractions are prepared and
+//          launched, the operand preparation publishes max |point|^2 when it exceeds gate_limit, and on the device the
+//          split-bf16 kernel runs iff it did not, the fp32 MFMA kernel iff it did (same test as the prod-marginals gate).
+// The quantity that cancels in d2 = |x|^2 + |y|^2 - 2 x.y is at most 4 max |p|^2; one fp32 ulp of it times the largest
+// bandwidth is the absolute error of the exponent, so the gate keeps alpha_max * 4 max|p|^2 <= LVAE_COND_LIMIT
+// (<= 2.4e-3 in the exponent, the bound the log-density gate uses).  Below it the six limb products kept of nine
+// differ from the fp32 contraction by <= 3 * 2^-24 of sum_d |x_d y_d| (measured: tools/accuracy_paths.py).
+// Measured crossover (tools/bench_bf16x3.py: tts statistic at n = 16,384, 0.52 -> 0.45 ms): 2^27 pairs.
+#define LVAE_MMD_BX_MIN_PAIRS 134217728.0
+struct KsumMode {
+    bool wide, bx, gated;
+    float gate_limit;        // on max |p|^2 (gated only)
+};
+static int ksum_mode(int path, const PairPlan& p, int64_t na, int64_t nb, float alpha_max, bool perm, KsumMode* m) {
+    LVAE_CHECK_ARG(path == LVAE_PATH_AUTO || path == LVAE_PATH_MFMA || path == LVAE_PATH_DIRECT ||
+                       path == LVAE_PATH_MFMA_BF16X3, "unknown path %d", path);
+    *m = KsumMode{false, false, false, -1.f};
+    if (path == LVAE_PATH_DIRECT || p.DP == 0) {
+        if (perm) return lvae_set_error(LVAE_ERR_UNSUPPORTED, "the permutation test has no direct-difference form (D <= 256, paths AUTO / MFMA / MFMA_BF16X3)");
+        if (p.DP == 0 && (path == LVAE_PATH_MFMA || path == LVAE_PATH_MFMA_BF16X3))
+            return lvae_set_error(LVAE_ERR_UNSUPPORTED, "the matrix-core kernel sums need D <= 256");
+        m->wide = true;
+        return LVAE_OK;
+    }
+    if (path == LVAE_PATH_MFMA_BF16X3) {
+        if (!lvae_bf16x3_supported(p.DP))
+            return lvae_set_error(LVAE_ERR_UNSUPPORTED, "the split-bf16 kernel sums need D <= 128");
+        m->bx = true;
+        return LVAE_OK;
+    }
+    if (path == LVAE_PATH_AUTO && lvae_bf16x3_supported(p.DP) && alpha_max > 0.f) {
+        const long long forced = lvae_switches().mmd_bx_min_pairs;
+        const double min_pairs = forced >= 0 ? (double)forced : LVAE_MMD_BX_MIN_PAIRS;
+        if ((double)na * (double)nb >= min_pairs) {
+            m->bx = m->gated = true;
+            m->gate_limit = LVAE_COND_LIMIT / (4.0f * alpha_max);
+        }
+    }
     return LVAE_OK;
 }
-
-extern "C" int lvae_get_pair_math(void) { return g_pair_math.load(); }
-
-static bool ksum_use_bx(const PairPlan& p) {
-    return g_pair_math.load() == LVAE_MATH_BF16X3 && lvae_bf16x3_supported(p.DP);
+// gated passes keep the fp32 operands of the other branch behind the plan's own regions
+static size_t ksum_gate_extra(const PairPlan& p) {
+    if (!lvae_bf16x3_supported(p.DP)) return 0;
+    return lvae_align256((size_t)p.nblk * p.DP * 64 * sizeof(float)) + lvae_align256((size_t)p.cpad * 2 * p.DP * sizeof(float));
+}
+struct KsumRegions {
+    PairHeader* hdr;
+    float *rfrag, *rbias, *cop, *colnorm, *rfrag32, *cop32;
+    float2* partial;
+};
+static KsumRegions ksum_regions(const PairPlan& p, void* ws) {
+    char* base = (char*)ws;
+    KsumRegions r;
+    r.hdr = (PairHeader*)(base + p.off_hdr);
+    r.rfrag = (float*)(base + p.off_rfrag);
+    r.rbias = (float*)(base + p.off_rbias);
+    r.cop = (float*)(base + p.off_cop);
+    r.colnorm = (float*)(base + p.off_colbias);
+    r.partial = (float2*)(base + p.off_partial);
+    r.rfrag32 = (float*)(base + p.total);
+    r.cop32 = (float*)(base + p.total + lvae_align256((size_t)p.nblk * p.DP * 64 * sizeof(float)));
+    return r;
 }
 
 // Operands of a kernel-sum pass: reduced axis = points b (linear-only POINT rows -2b, fragment-major, + |b|^2
-// biases), kept axis = points a (linear-only SAMPLE rows, + |a|^2 into colnorm).  bx: the limb operands replace
-// the fp32 ones in the same regions (the fp32 prep still writes the biases and the norms).
-static int prep_ksum_operands(const PairPlan& p, bool bx, const float* a, int64_t na, const float* b, int64_t nb,
-                              int D, PairHeader* hdr, float* rfrag, float* rbias, float* cop, float* colnorm,
-                              hipStream_t st) {
-    int rc = lvae_launch_prep(3, true, b, nullptr, 0, nb, p.nblk * 32, D, p.DP, hdr, 1, bx ? nullptr : rfrag, rbias,
-                              nullptr, p.DC, st);
+// biases), kept axis = points a (linear-only SAMPLE rows, + |a|^2 into colnorm).  bx: the limb operands go to the
+// plan's regions (the fp32 prep still writes the biases and the norms); gated: the fp32 operands as well, behind them.
+static int prep_ksum_operands(const PairPlan& p, const KsumMode& m, const float* a, int64_t na, const float* b, int64_t nb,
+                              int D, const KsumRegions& r, hipStream_t st) {
+    float* rf32 = m.gated ? r.rfrag32 : (m.bx ? nullptr : r.rfrag);
+    float* cop32 = m.gated ? r.cop32 : (m.bx ? nullptr : r.cop);
+    const float floor = m.gated ? m.gate_limit : -1.f;
+    int rc = lvae_launch_prep(3, true, b, nullptr, 0, nb, p.nblk * 32, D, p.DP, r.hdr, 1, rf32, r.rbias, nullptr, p.DC, st,
+                              floor);
     if (rc) return rc;
-    rc = lvae_launch_prep(4, false, a, nullptr, 0, na, p.cpad, D, p.DP, hdr, 1, bx ? nullptr : cop, colnorm, nullptr,
-                          p.DC, st);
-    if (rc || !bx) return rc;
-    rc = lvae_launch_prep_bf16x3(3, true, b, nullptr, 0, nb, p.nblk * 32, D, p.DP, hdr, 1, rfrag, st);
+    rc = lvae_launch_prep(4, false, a, nullptr, 0, na, p.cpad, D, p.DP, r.hdr, 1, cop32, r.colnorm, nullptr, p.DC, st,
+                          floor);
+    if (rc || !m.bx) return rc;
+    rc = lvae_launch_prep_bf16x3(3, true, b, nullptr, 0, nb, p.nblk * 32, D, p.DP, r.hdr, 1, r.rfrag, st);
     if (rc) return rc;
-    return lvae_launch_prep_bf16x3(4, false, a, nullptr, 0, na, p.cpad, D, p.DP, hdr, 1, cop, st);
+    return lvae_launch_prep_bf16x3(4, false, a, nullptr, 0, na, p.cpad, D, p.DP, r.hdr, 1, r.cop, st);
+}
+
+// The pair launch(es) of one kernel-sum pass under its mode.
+static int launch_ksum_pair(const PairPlan& p, const KsumMode& m, const KsumRegions& r, bool excl, int64_t excl_offset,
+                            int epi, int sym, hipStream_t st) {
+    if (!m.bx)
+        return lvae_launch_pair_mfma(p, r.rfrag, r.rbias, r.cop, r.partial, r.hdr, -1.f, 0, excl, excl_offset, epi, nullptr,
+                                     sym, r.colnorm, st);
+    int rc = lvae_launch_pair_bf16x3(p, r.rfrag, r.rbias, r.cop, r.partial, r.hdr, m.gated ? m.gate_limit : -1.f, 0, excl,
+                                     excl_offset, epi, nullptr, sym, r.colnorm, st);
+    if (rc || !m.gated) return rc;
+    return lvae_launch_pair_mfma(p, r.rfrag32, r.rbias, r.cop32, r.partial, r.hdr, m.gate_limit, 1, excl, excl_offset, epi,
+                                 nullptr, sym, r.colnorm, st);
 }
 
 static int ksum_pass(const float* a, int64_t na, const float* b, int64_t nb, int D, bool excl, int epi,
-                     void* ws, size_t ws_extent, double* out, hipStream_t st) {
+                     const KsumMode& m, void* ws, size_t ws_extent, double* out, hipStream_t st) {
     const PairPlan p = lvae_make_pair_plan(nb, na, ksum_plan_dim(D), false, 0, a == b);
-    if (p.total > ws_extent)
+    int rc;
+    if (p.total + (m.gated ? ksum_gate_extra(p) : 0) > ws_extent)
         return lvae_set_error(LVAE_ERR_WORKSPACE, "internal: kernel-sum pass needs %zu bytes, %zu reserved", p.total,
                               ws_extent);
-    char* base = (char*)ws;
-    PairHeader* hdr = (PairHeader*)(base + p.off_hdr);
-    float* rfrag = (float*)(base + p.off_rfrag);
-    float* rbias = (float*)(base + p.off_rbias);
-    float* cop = (float*)(base + p.off_cop);
-    float2* partial = (float2*)(base + p.off_partial);
-    int rc;
-    if (p.DP == 0) {      // D > 256: direct differences on the vector ALU (no symmetric walk)
-        rc = lvae_launch_ksum_wide(a, b, na, nb, D, hdr, excl, 0, p.nsplit, p.cpad, (double*)partial, st);
+    const KsumRegions r = ksum_regions(p, ws);
+    if (m.wide) {         // direct differences on the vector ALU (no symmetric walk)
+        rc = lvae_launch_ksum_wide(a, b, na, nb, D, r.hdr, excl, 0, p.nsplit, p.cpad, (double*)r.partial, st);
     } else {
-        const bool bx = ksum_use_bx(p);
-        float* colnorm = (float*)(base + p.off_colbias);
-        rc = prep_ksum_operands(p, bx, a, na, b, nb, D, hdr, rfrag, rbias, cop, colnorm, st);
+        rc = prep_ksum_operands(p, m, a, na, b, nb, D, r, st);
         if (rc) return rc;
-        rc = (bx ? lvae_launch_pair_bf16x3 : lvae_launch_pair_mfma)(p, rfrag, rbias, cop, partial, hdr, -1.f, 0, excl,
-                                                                    0, epi, nullptr, a == b ? 1 : 0, colnorm, st);
+        rc = launch_ksum_pair(p, m, r, excl, 0, epi, a == b ? 1 : 0, st);
     }
     if (rc) return rc;
-    return lvae_launch_finalize_ksum((const double*)partial, p.nsplit, p.cpad, na, out, st);
+    return lvae_launch_finalize_ksum((const double*)r.partial, p.nsplit, p.cpad, na, out, st);
 }
 
 extern "C" int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int64_t n2, int D,
-                                const float* alphas, int n_alpha, float dist_eps, int unbiased, double* out,
+                                const float* alphas, int n_alpha, float dist_eps, int unbiased, int path, double* out,
                                 void* ws, int64_t ws_bytes, void* stream) {
     LVAE_CHECK_ARG(x && y && out, "x, y and out must be non-NULL");
     LVAE_CHECK_ARG(n1 >= 2 && n2 >= 2, "need n1, n2 >= 2");
@@ -1307,12 +1410,17 @@ extern "C" int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int6
     LVAE_CHECK_ARG(n1 < (1LL << 31) && n2 < (1LL << 31), "n1, n2 must be below 2^31");
     KsumParams kp;
     int zeros = 0;
-    int rc = build_ksum(alphas, n_alpha, dist_eps, &kp, &zeros);
+    float alpha_max = 0.f;
+    int rc = build_ksum(alphas, n_alpha, dist_eps, &kp, &zeros, &alpha_max);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const bool all_zero = kp.n == 0 && kp.c[0] == 0.f;
-    if (!all_zero && mmd_fused_dims(D) && g_pair_math.load() == LVAE_MATH_FP32 &&
-        lvae_pair_multi_supported(lvae_pad_dim(ksum_plan_dim(D)), ksum_epi(kp)) && !getenv("LVAE_NO_FUSED_MMD")) {
+    // the fused fp32 form serves LVAE_PATH_MFMA, and LVAE_PATH_AUTO wherever AUTO stays on fp32 (small problems)
+    KsumMode mxy;
+    rc = ksum_mode(path, lvae_make_pair_plan(n2, n1, ksum_plan_dim(D), false, 0, false), n1, n2, alpha_max, false, &mxy);
+    if (rc) return rc;
+    if (!all_zero && mmd_fused_dims(D) && !mxy.bx && !mxy.wide &&
+        lvae_pair_multi_supported(lvae_pad_dim(ksum_plan_dim(D)), ksum_epi(kp)) && !lvae_switches().no_fused_mmd) {
         // ---- fused form: five launches (init, one operand prep, one pair launch for the three matrices, one total,
         //      the statistic) instead of eighteen
         const MmdFusedLayout L = mmd_fused_layout(n1, n2, D);
@@ -1376,11 +1484,13 @@ extern "C" int lvae_mmd_rbf_f32(const float* x, const float* y, int64_t n1, int6
         LVAE_HIP(hipMemsetAsync(sums, 0, 3 * sizeof(double), st));
     } else {
         const int epi = ksum_epi(kp);
-        rc = ksum_pass(x, n1, x, n1, D, excl, epi, ws, extent, sums + 0, st);
+        // (one mode for the three passes, the cross term's: a statistic is one contraction throughout, and the gate's
+        //  estimate -- the largest squared norm of either sample, kept in the header across the passes -- is shared)
+        rc = ksum_pass(x, n1, x, n1, D, excl, epi, mxy, ws, extent, sums + 0, st);
         if (rc) return rc;
-        rc = ksum_pass(y, n2, y, n2, D, excl, epi, ws, extent, sums + 1, st);
+        rc = ksum_pass(y, n2, y, n2, D, excl, epi, mxy, ws, extent, sums + 1, st);
         if (rc) return rc;
-        rc = ksum_pass(x, n1, y, n2, D, false, epi, ws, extent, sums + 2, st);
+        rc = ksum_pass(x, n1, y, n2, D, false, epi, mxy, ws, extent, sums + 2, st);
         if (rc) return rc;
     }
     return lvae_launch_mmd_stat(sums, n1, n2, unbiased, zeros, out, st);
@@ -1396,7 +1506,7 @@ extern "C" int lvae_kernel_sum_workspace_bytes(int64_t na, int64_t nb, int D, in
 
 extern "C" int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, int64_t nb, int D,
                                    const float* alphas, int n_alpha, float dist_eps, int exclude_diag,
-                                   int64_t diag_offset, int symmetric, double* out_total, double* out_colsum,
+                                   int64_t diag_offset, int symmetric, int path, double* out_total, double* out_colsum,
                                    void* ws, int64_t ws_bytes, void* stream) {
     LVAE_CHECK_ARG(a && b, "a and b must be non-NULL");
     LVAE_CHECK_ARG(out_total || out_colsum, "at least one of out_total / out_colsum is required");
@@ -1407,40 +1517,36 @@ extern "C" int lvae_kernel_sum_f32(const float* a, const float* b, int64_t na, i
                    "symmetric evaluation: a must be rows diag_offset.. of b, diag_offset %% 32 == 0, totals only");
     KsumParams kp;
     int zeros = 0;
-    int rc = build_ksum(alphas, n_alpha, dist_eps, &kp, &zeros);
+    float alpha_max = 0.f;
+    int rc = build_ksum(alphas, n_alpha, dist_eps, &kp, &zeros, &alpha_max);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int sym = symmetric != 0;
     const PairPlan p = lvae_make_pair_plan(nb, na, ksum_plan_dim(D), false, 0, sym);
-    rc = check_ws(ws, ws_bytes, p.total);
+    KsumMode m;
+    rc = ksum_mode(path, p, na, nb, alpha_max, false, &m);
     if (rc) return rc;
-    char* base = (char*)ws;
-    PairHeader* hdr = (PairHeader*)(base + p.off_hdr);
-    float2* partial = (float2*)(base + p.off_partial);
-    LVAE_HIP(hipMemsetAsync(hdr, 0, sizeof(PairHeader), st));   // colsum = 0 -> no centering shift
-    rc = lvae_launch_set_ksum(hdr, kp, st);
+    rc = check_ws(ws, ws_bytes, p.total + (m.gated ? ksum_gate_extra(p) : 0));
+    if (rc) return rc;
+    const KsumRegions r = ksum_regions(p, ws);
+    LVAE_HIP(hipMemsetAsync(r.hdr, 0, sizeof(PairHeader), st));   // colsum = 0 -> no centering shift
+    rc = lvae_launch_set_ksum(r.hdr, kp, st);
     if (rc) return rc;
     if (kp.n == 0 && kp.c[0] == 0.f) {      // only alpha = 0 bandwidths: no pair kernel needed
-        LVAE_HIP(hipMemsetAsync(partial, 0, (size_t)p.nsplit * p.cpad * sizeof(double), st));
+        LVAE_HIP(hipMemsetAsync(r.partial, 0, (size_t)p.nsplit * p.cpad * sizeof(double), st));
+    } else if (m.wide) {
+        // direct differences on the vector ALU; every pair of the owned rows is evaluated (a symmetric request is
+        // served as a plain one: the owners' totals still add up)
+        rc = lvae_launch_ksum_wide(a, b, na, nb, D, r.hdr, exclude_diag != 0, diag_offset, p.nsplit, p.cpad,
+                                   (double*)r.partial, st);
+        if (rc) return rc;
     } else {
-        if (p.DP == 0) {  // D > 256: direct differences on the vector ALU; every pair of the owned rows is evaluated
-                          // (a symmetric request is served as a plain one: the owners' totals still add up)
-            rc = lvae_launch_ksum_wide(a, b, na, nb, D, hdr, exclude_diag != 0, diag_offset, p.nsplit, p.cpad,
-                                       (double*)partial, st);
-            if (rc) return rc;
-        } else {
-            const bool bx = ksum_use_bx(p);
-            float* colnorm = (float*)(base + p.off_colbias);
-            rc = prep_ksum_operands(p, bx, a, na, b, nb, D, hdr, (float*)(base + p.off_rfrag),
-                                    (float*)(base + p.off_rbias), (float*)(base + p.off_cop), colnorm, st);
-            if (rc) return rc;
-            rc = (bx ? lvae_launch_pair_bf16x3 : lvae_launch_pair_mfma)(
-                p, (float*)(base + p.off_rfrag), (float*)(base + p.off_rbias), (float*)(base + p.off_cop), partial,
-                hdr, -1.f, 0, exclude_diag != 0, diag_offset, ksum_epi(kp), nullptr, sym, colnorm, st);
-            if (rc) return rc;
-        }
+        rc = prep_ksum_operands(p, m, a, na, b, nb, D, r, st);
+        if (rc) return rc;
+        rc = launch_ksum_pair(p, m, r, exclude_diag != 0, diag_offset, ksum_epi(kp), sym, st);
+        if (rc) return rc;
     }
-    return lvae_launch_ksum_columns((const double*)partial, p.nsplit, p.cpad, na, nb, exclude_diag != 0,
+    return lvae_launch_ksum_columns((const double*)r.partial, p.nsplit, p.cpad, na, nb, exclude_diag != 0,
                                     diag_offset, zeros, out_colsum, out_total, st);
 }
 
@@ -1451,8 +1557,10 @@ static size_t perm_diag_bytes(const PairPlan& p) { return lvae_align256((size_t)
 static PairPlan perm_plan(int64_t nc, int64_t n, int D, bool sym) {
     return lvae_make_pair_plan(n, nc, ksum_plan_dim(D), false, 1, sym);
 }
+// (label fragments, diagonal sums and the q_p accumulators sit behind the largest -- gated -- operand layout)
+static size_t perm_tail_offset(const PairPlan& p) { return p.total + ksum_gate_extra(p); }
 static size_t perm_extent(const PairPlan& p) {
-    return p.total + perm_labfrag_bytes(p) + perm_diag_bytes(p) + 256 * sizeof(double);
+    return perm_tail_offset(p) + perm_labfrag_bytes(p) + perm_diag_bytes(p) + 256 * sizeof(double);
 }
 
 extern "C" int lvae_mmd_perm_workspace_bytes(int64_t nc, int64_t n, int D, int64_t* out_bytes) {
@@ -1465,7 +1573,7 @@ extern "C" int lvae_mmd_perm_workspace_bytes(int64_t nc, int64_t n, int D, int64
 
 extern "C" int lvae_mmd_perm_f32(const float* cols, int64_t nc, int64_t col_offset, const float* pooled,
                                  int64_t n, int D, const unsigned char* labels, int P, const float* alphas,
-                                 int n_alpha, float dist_eps, int symmetric, double* out, void* ws,
+                                 int n_alpha, float dist_eps, int symmetric, int path, double* out, void* ws,
                                  int64_t ws_bytes, void* stream) {
     LVAE_CHECK_ARG(cols && pooled && labels && out, "cols, pooled, labels and out must be non-NULL");
     LVAE_CHECK_ARG(n >= 2 && nc >= 1 && col_offset >= 0 && col_offset + nc <= n,
@@ -1476,25 +1584,29 @@ extern "C" int lvae_mmd_perm_f32(const float* cols, int64_t nc, int64_t col_offs
     LVAE_CHECK_ARG(!symmetric || col_offset % 32 == 0, "symmetric evaluation needs col_offset %% 32 == 0");
     KsumParams kp;
     int zeros = 0;
-    int rc = build_ksum(alphas, n_alpha, dist_eps, &kp, &zeros);
+    float alpha_max = 0.f;
+    int rc = build_ksum(alphas, n_alpha, dist_eps, &kp, &zeros, &alpha_max);
     if (rc) return rc;
     (void)zeros;      // alpha == 0 bandwidths are left out of q, lr and T (lvae.h): they cancel in the statistic
     hipStream_t st = (hipStream_t)stream;
     const int sym = symmetric != 0;
     const PairPlan p = perm_plan(nc, n, D, sym);
+    KsumMode m;
+    rc = ksum_mode(path, p, nc, n, alpha_max, true, &m);
+    if (rc) return rc;
     const size_t lab_bytes = perm_labfrag_bytes(p);
     const size_t diag_bytes = perm_diag_bytes(p);
     rc = check_ws(ws, ws_bytes, perm_extent(p));      // the extent of the layout used below, not of another mode's plan
     if (rc) return rc;
     char* base = (char*)ws;
-    PairHeader* hdr = (PairHeader*)(base + p.off_hdr);
-    float2* partial = (float2*)(base + p.off_partial);
-    void* labfrag = base + p.total;
-    double* diag_partial = (double*)(base + p.total + lab_bytes);
-    double* qperm = (double*)(base + p.total + lab_bytes + diag_bytes);
-    LVAE_HIP(hipMemsetAsync(hdr, 0, sizeof(PairHeader), st));
+    const KsumRegions r = ksum_regions(p, ws);
+    const size_t tail = perm_tail_offset(p);
+    void* labfrag = base + tail;
+    double* diag_partial = (double*)(base + tail + lab_bytes);
+    double* qperm = (double*)(base + tail + lab_bytes + diag_bytes);
+    LVAE_HIP(hipMemsetAsync(r.hdr, 0, sizeof(PairHeader), st));
     LVAE_HIP(hipMemsetAsync(qperm, 0, 256 * sizeof(double), st));
-    rc = lvae_launch_set_ksum(hdr, kp, st);
+    rc = lvae_launch_set_ksum(r.hdr, kp, st);
     if (rc) return rc;
     if (kp.n == 0 && kp.c[0] == 0.f) {      // only alpha = 0 bandwidths: the statistic is identically 0
         LVAE_HIP(hipMemsetAsync(out, 0, (2 * (size_t)P + 1) * sizeof(double), st));
@@ -1502,10 +1614,7 @@ extern "C" int lvae_mmd_perm_f32(const float* cols, int64_t nc, int64_t col_offs
     }
     rc = lvae_launch_prep_labels(labels, P, n, p.nblk, labfrag, st);
     if (rc) return rc;
-    const bool bx = ksum_use_bx(p);
-    float* colnorm = (float*)(base + p.off_colbias);
-    rc = prep_ksum_operands(p, bx, cols, nc, pooled, n, D, hdr, (float*)(base + p.off_rfrag),
-                            (float*)(base + p.off_rbias), (float*)(base + p.off_cop), colnorm, st);
+    rc = prep_ksum_operands(p, m, cols, nc, pooled, n, D, r, st);
     if (rc) return rc;
     PermArgs pa{};
     pa.labfrag = labfrag;
@@ -1516,11 +1625,21 @@ extern "C" int lvae_mmd_perm_f32(const float* cols, int64_t nc, int64_t col_offs
     pa.col_offset = col_offset;
     pa.C = nc;
     pa.P = P;
-    rc = (bx ? lvae_launch_pair_bf16x3_perm : lvae_launch_pair_mfma_perm)(
-        p, (float*)(base + p.off_rfrag), (float*)(base + p.off_rbias), (float*)(base + p.off_cop), partial, hdr,
-        col_offset, ksum_epi(kp), pa, sym, colnorm, st);
+    const int epi = ksum_epi(kp);
+    if (!m.bx) {
+        rc = lvae_launch_pair_mfma_perm(p, r.rfrag, r.rbias, r.cop, r.partial, r.hdr, -1.f, 0, col_offset, epi, pa, sym,
+                                        r.colnorm, st);
+    } else {
+        // gated (LVAE_PATH_AUTO): both forms are launched, the device-side test on the operand preparation's estimate
+        // lets exactly one of them run
+        rc = lvae_launch_pair_bf16x3_perm(p, r.rfrag, r.rbias, r.cop, r.partial, r.hdr, m.gated ? m.gate_limit : -1.f, 0,
+                                          col_offset, epi, pa, sym, r.colnorm, st);
+        if (!rc && m.gated)
+            rc = lvae_launch_pair_mfma_perm(p, r.rfrag32, r.rbias, r.cop32, r.partial, r.hdr, m.gate_limit, 1, col_offset,
+                                            epi, pa, sym, r.colnorm, st);
+    }
     if (rc) return rc;
-    return lvae_launch_perm_lr((const double*)partial, diag_partial, p.nsplit, p.cpad, nc, labels, n, col_offset,
+    return lvae_launch_perm_lr((const double*)r.partial, diag_partial, p.nsplit, p.cpad, nc, labels, n, col_offset,
                                P, sym, qperm, out, st);
 }
 
@@ -1531,7 +1650,7 @@ extern "C" int lvae_layout_info(int kind, int64_t na, int64_t nb, int D, int sym
     const bool sym = symmetric != 0;
     if (kind == 0) {
         const PairPlan p = lvae_make_pair_plan(nb, na, ksum_plan_dim(D), false, 0, sym);
-        out[0] = (int64_t)p.total; out[1] = p.nsplit; out[2] = p.cpad;
+        out[0] = (int64_t)(p.total + ksum_gate_extra(p)); out[1] = p.nsplit; out[2] = p.cpad;
     } else if (kind == 1) {
         const PairPlan p = perm_plan(na, nb, D, sym);
         out[0] = (int64_t)perm_extent(p); out[1] = p.nsplit; out[2] = p.cpad;
@@ -1540,7 +1659,7 @@ extern "C" int lvae_layout_info(int kind, int64_t na, int64_t nb, int D, int sym
         const PairPlan p = symmetric == 0 ? lvae_make_pair_plan(nb, na, ksum_plan_dim(D), false, 0, false)
                          : symmetric == 1 ? lvae_make_pair_plan(na, na, ksum_plan_dim(D), false, 0, true)
                                           : lvae_make_pair_plan(nb, nb, ksum_plan_dim(D), false, 0, true);
-        out[0] = (int64_t)p.total + 256; out[1] = p.nsplit; out[2] = p.cpad;
+        out[0] = (int64_t)(p.total + ksum_gate_extra(p)) + 256; out[1] = p.nsplit; out[2] = p.cpad;
     } else {
         return lvae_set_error(LVAE_ERR_INVALID, "unknown layout kind %d", kind);
     }

@@ -41,6 +41,25 @@ int lvae_set_error(int status, const char* fmt, ...);
 
 #define LVAE_LAUNCH_CHECK() LVAE_HIP(hipGetLastError())
 
+// ---- development switches (environment variables), read ONCE per process ---------------------------------------
+// Sweeps and tests that change the environment mid-process call lvae_dev_reload_env() afterwards (lvae_api.hip owns
+// the storage); product calls never touch getenv.
+struct LvaeSwitches {
+    long long nsplit, dsplit;     // LVAE_NSPLIT / LVAE_DSPLIT: forced split counts of the plan (0: the plan decides)
+    double small_pairs;           // LVAE_SMALL_PAIRS: threshold of the small path (< 0: built-in)
+    bool no_small_path;           // LVAE_NO_SMALL_PATH
+    int prep_rb;                  // LVAE_PREP_RB: blocks per workgroup of the operand prep (0: unset; set = separate launches)
+    bool no_fused_tail;           // LVAE_NO_FUSED_TAIL
+    bool no_fused_mmd;            // LVAE_NO_FUSED_MMD
+    int bwd_path;                 // LVAE_BWD_PATH: 0 unset, 1 valu, 2 mfma
+    int iw_pipe;                  // LVAE_IW_PIPE: -1 unset, 0 / 1
+    int iw_u, iw_tpb;             // LVAE_IW_U / LVAE_IW_TPB (0: unset)
+    bool iw_no_stage;             // LVAE_IW_NO_STAGE
+    int iw_batch;                 // LVAE_IW_BATCH: sentences per workgroup of the density-writing IW form (0: built-in)
+    long long mmd_bx_min_pairs;   // LVAE_MMD_BX_MIN_PAIRS: smallest n1*n2 at which AUTO takes the split-bf16 kernel sums (< 0: built-in)
+};
+const LvaeSwitches& lvae_switches();
+
 static inline int64_t lvae_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t lvae_round_up(int64_t a, int64_t b) { return lvae_ceil_div(a, b) * b; }
 

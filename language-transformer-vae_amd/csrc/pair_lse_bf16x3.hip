@@ -168,28 +168,30 @@ int lvae_launch_pair_bf16x3(const PairPlan& p, const float* rfrag, const float* 
 // Kernel-matrix column sums plus label-permutation sums: same contract as lvae_launch_pair_mfma_perm.
 template <int DP, int WPS>
 static int launch_bx_perm(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
-                          float2* partial, const PairHeader* hdr, int64_t excl_offset, int epi,
-                          const PermArgs& pa, int sym, const float* colnorm, hipStream_t st) {
+                          float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
+                          int64_t excl_offset, int epi, const PermArgs& pa, int sym, const float* colnorm,
+                          hipStream_t st) {
     const dim3 grid((unsigned)(p.cpad / (4 * 32)), (unsigned)p.nsplit);
     if (epi == 1)
         hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 1, true, true>), grid, dim3(256), 0, st, rfrag,
-                           rbias, cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr,
+                           rbias, cop, partial, hdr, cond_limit, use_if_above, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr,
                            sym, colnorm);
     else if (epi == 2)
         hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 2, true, true>), grid, dim3(256), 0, st, rfrag,
-                           rbias, cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr,
+                           rbias, cop, partial, hdr, cond_limit, use_if_above, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr,
                            sym, colnorm);
     else
         hipLaunchKernelGGL((pair_lse_mfma_kernel<DP, 1, WPS, true, 5, true, true>), grid, dim3(256), 0, st, rfrag,
-                           rbias, cop, partial, hdr, -1.f, 0, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr,
+                           rbias, cop, partial, hdr, cond_limit, use_if_above, p.nblk, p.blk_per_split, p.cpad, excl_offset, pa, nullptr,
                            sym, colnorm);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }
 
 int lvae_launch_pair_bf16x3_perm(const PairPlan& p, const float* rfrag, const float* rbias, const float* cop,
-                                 float2* partial, const PairHeader* hdr, int64_t excl_offset, int epi,
-                                 const PermArgs& pa, int sym, const float* colnorm, hipStream_t st) {
+                                 float2* partial, const PairHeader* hdr, float cond_limit, int use_if_above,
+                                 int64_t excl_offset, int epi, const PermArgs& pa, int sym, const float* colnorm,
+                                 hipStream_t st) {
     if (sym && pa.col_offset % 32 != 0)
         return lvae_set_error(LVAE_ERR_INVALID, "symmetric permutation sums need col_offset %% 32 == 0");
     if (p.NCB != 1 || p.cpad % 128 != 0)
@@ -201,9 +203,9 @@ int lvae_launch_pair_bf16x3_perm(const PairPlan& p, const float* rfrag, const fl
     if (pa.P < 1 || pa.P > 128) return lvae_set_error(LVAE_ERR_INVALID, "need 1 <= labelings <= 128 per pass");
     if (!colnorm) return lvae_set_error(LVAE_ERR_INVALID, "kernel-sum epilogues need the per-column norms");
     switch (p.DP) {
-        case 16: return launch_bx_perm<16, 2>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, colnorm, st);
-        case 32: return launch_bx_perm<32, 2>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, colnorm, st);
-        case 64: return launch_bx_perm<64, 1>(p, rfrag, rbias, cop, partial, hdr, excl_offset, epi, pa, sym, colnorm, st);
+        case 16: return launch_bx_perm<16, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl_offset, epi, pa, sym, colnorm, st);
+        case 32: return launch_bx_perm<32, 2>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl_offset, epi, pa, sym, colnorm, st);
+        case 64: return launch_bx_perm<64, 1>(p, rfrag, rbias, cop, partial, hdr, cond_limit, use_if_above, excl_offset, epi, pa, sym, colnorm, st);
         default:
             return lvae_set_error(LVAE_ERR_UNSUPPORTED, "the bf16x3 path needs D <= 64 (got D=%d)", p.D);
     }

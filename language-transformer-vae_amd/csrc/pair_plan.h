@@ -145,12 +145,12 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
     // split count that minimises it (a grid of 543 equal workgroups on 512 slots would take two full rounds).
     // At least five rounds' worth of workgroups (sym: uneven work per workgroup -> eight) when the axis allows.
     const int64_t groups = p.DP ? p.cpad / (4 * 32 * p.NCB) : 1;
-    const char* tw_env = getenv("LVAE_NSPLIT");
+    const int64_t ns_forced = lvae_switches().nsplit;
     const int64_t slots = 256 * ((p.DP == 128 && !lse) ? 1 : 2);
     const int64_t max_ns = p.nblk < 64 ? (p.nblk < 1 ? 1 : p.nblk) : 64;
     int64_t ns = 1;
-    if (tw_env) {
-        ns = atoll(tw_env);
+    if (ns_forced) {
+        ns = ns_forced;
     } else {
         // (1) The many-rounds rule, measured at C2 (N = M = 65,536): five rounds of smaller workgroups beat one round
         //     of large ones by 2.4 % (sym: eight, the work per workgroup is uneven) -- as long as a split keeps
@@ -220,8 +220,7 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
         const int64_t dgroups = p.cpad / 256 > 0 ? p.cpad / 256 : 1;
         const int64_t target = dgroups >= 192 ? 4608 : (dgroups >= 96 ? 1536 : 768);
         int64_t ds = lvae_ceil_div(target, dgroups);
-        const char* ds_env = getenv("LVAE_DSPLIT");
-        if (ds_env) ds = atoll(ds_env);
+        if (lvae_switches().dsplit) ds = lvae_switches().dsplit;
         if (ds > R / 128) ds = R / 128;
         if (ds > 64) ds = 64;
         if (ds < 1) ds = 1;

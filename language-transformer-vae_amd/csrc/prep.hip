@@ -204,6 +204,10 @@ prep_rows(const int64_t wg, const int rb, const float* __restrict__ x, const flo
                 cond += __shfl_xor(cond, off, 64);
                 nsum += __shfl_xor(nsum, off, 64);
             }
+            // kernel sums behind the split-bf16 gate (lvae_api.hip, KsumMode): a squared norm above the gate's limit is
+            // published (the rare case; ordinary inputs issue no atomics)
+            if (LIN && valid && q == 0 && cond_floor >= 0.f && csum > cond_floor)
+                atomicMax(&hdr->cond_bits, __float_as_uint(csum));
             if (bias && q == 0 && row < npad) {
                 float bv = GAUSS ? -0.5f * LVAE_LOG2E * csum : ((POINT || LIN) ? csum : 0.f);
                 if (!valid) bv = FRAG ? ((POINT || LIN) ? INFINITY : -INFINITY) : 0.f;
@@ -585,7 +589,7 @@ int lvae_launch_prep(int src, bool frag, const float* x, const float* spread, in
                      float* out, float* bias, float* dparams, int DC, hipStream_t st, float cond_floor) {
     const int threads = 32 * (DP / 4);
     int rb = PREP_RB;
-    if (getenv("LVAE_PREP_RB")) rb = atoi(getenv("LVAE_PREP_RB")) > 0 ? atoi(getenv("LVAE_PREP_RB")) : rb;   // (sweeps)
+    if (lvae_switches().prep_rb > 0) rb = lvae_switches().prep_rb;   // (sweeps: LVAE_PREP_RB)
     const dim3 grid((unsigned)lvae_ceil_div(npad, 32 * rb));
     const double inv = 1.0 / (double)ngauss;
 #define LVAE_PREP(S, F)                                                                          \

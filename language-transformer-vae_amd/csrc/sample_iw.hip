@@ -406,8 +406,9 @@ int lvae_launch_sample_iw(bool from_eps, const float* mu, const float* logvar, c
         int umax = G < 8 ? G : 8;
         if (!(from_eps && z_out) && umax > 4) umax = 4;
         bool pipe = true;
-        if (getenv("LVAE_IW_PIPE")) pipe = atoi(getenv("LVAE_IW_PIPE")) != 0;
-        if (getenv("LVAE_IW_U") && atoi(getenv("LVAE_IW_U")) < umax) umax = atoi(getenv("LVAE_IW_U"));
+        const LvaeSwitches& sw = lvae_switches();
+        if (sw.iw_pipe >= 0) pipe = sw.iw_pipe != 0;
+        if (sw.iw_u > 0 && sw.iw_u < umax) umax = sw.iw_u;
         int tpb = K <= (64 / G) * umax ? 64 : (K <= (128 / G) * umax ? 128 : 256);
         const bool read_only = !(from_eps && z_out);
         // Read-only forms: the widest workgroup that still makes four passes over the sentence (a short sentence on
@@ -415,14 +416,14 @@ int lvae_launch_sample_iw(bool from_eps, const float* mu, const float* logvar, c
         // 0.232 ms at 256 threads, 0.178 at 128, 0.149 at 64; K = 200: 0.167 / 0.145 / 0.141; K = 400: all 0.141-0.145;
         // tools/sweep_iw_geometry.py).  When z is written the wider workgroups win (K = 200: 0.29 against 0.32).
         if (read_only) tpb = K >= (int64_t)4 * (256 / G) * umax ? 256 : (K >= (int64_t)4 * (128 / G) * umax ? 128 : 64);
-        if (getenv("LVAE_IW_TPB")) tpb = atoi(getenv("LVAE_IW_TPB"));      // (sweeps: 64, 128 or 256)
+        if (sw.iw_tpb) tpb = sw.iw_tpb;      // (sweeps: 64, 128 or 256)
         // few passes: the single-buffer form needs fewer registers (more waves)
-        if (K <= (int64_t)(tpb / G) * umax * (read_only ? 4 : 2) && !getenv("LVAE_IW_PIPE")) pipe = false;
+        if (K <= (int64_t)(tpb / G) * umax * (read_only ? 4 : 2) && sw.iw_pipe < 0) pipe = false;
         // [B,K] outputs through LDS (see the kernel): K a multiple of 4 from 256 (K = 100 measured 2 % slower) up to 2,048
         // (16 KB), 16-byte aligned rows; LVAE_IW_NO_STAGE=1 for comparisons
         const bool al16 = (((uintptr_t)log_q_z_x | (uintptr_t)log_p_z) & 15) == 0;
         const int stage = ((log_q_z_x || log_p_z) && K % 4 == 0 && K >= 256 && K <= 2048 && al16 &&
-                           !getenv("LVAE_IW_NO_STAGE")) ? 1 : 0;
+                           !sw.iw_no_stage) ? 1 : 0;
         const size_t dyn = stage ? (size_t)2 * K * sizeof(float) : 0;
 #define LVAE_SIW2(E, UU, T, P)                                                                             \
     hipLaunchKernelGGL((sample_iw_kernel<E, UU, T, P>), grid, dim3(T), dyn, st, mu, logvar, src, log_p_x_z, K, D, G, \

@@ -335,10 +335,11 @@ def gaussian_kernel(x, y):
     return _kernel_matrix(x.detach(), y.detach(), [1.0 / float(dim * dim)], 0.0)
 
 
-def mmd_rbf(x, y, alphas, dist_eps, unbiased):
+def mmd_rbf(x, y, alphas, dist_eps, unbiased, path=N.PATH_AUTO):
     """Gaussian-kernel MMD between samples x [n1,D] and y [n2,D] without materialising the kernel
     matrices (fused MFMA distance + kernel-sum pass).  Returns a float64 device tensor
-    [statistic, sum Kxx, sum Kyy, sum Kxy]."""
+    [statistic, sum Kxx, sum Kyy, sum Kxy].  ``path``: contraction of the distance (include/lvae.h; AUTO: fp32 MFMA on
+    small problems, the gated split-bf16 form from 2^27 pairs on)."""
     x, y = N.as_f32(x, "x"), N.as_f32(y, "y")
     if x.dim() != 2 or y.dim() != 2 or x.shape[1] != y.shape[1]:
         raise ValueError("x and y must be [n1, D] and [n2, D]")
@@ -351,12 +352,13 @@ def mmd_rbf(x, y, alphas, dist_eps, unbiased):
         ws = N.workspace(nbytes.value, dev)
         out = torch.empty(4, dtype=torch.float64, device=dev)
         N.check(N.lib().lvae_mmd_rbf_f32(N.ptr(x), N.ptr(y), n1, n2, D, arr, na, float(dist_eps),
-                                         int(bool(unbiased)), N.ptr(out), N.ptr(ws), nbytes.value,
+                                         int(bool(unbiased)), int(path), N.ptr(out), N.ptr(ws), nbytes.value,
                                          N.stream_ptr(dev)))
     return out
 
 
-def kernel_sum(a, b, alphas, dist_eps, exclude_diag=False, diag_offset=0, colsum=False, symmetric=False):
+def kernel_sum(a, b, alphas, dist_eps, exclude_diag=False, diag_offset=0, colsum=False, symmetric=False,
+               path=N.PATH_AUTO):
     """sum_{i,j} k(a_i, b_j) with k = sum_alpha exp(-alpha (dist_eps + |a_i - b_j|^2)), optionally
     without the pairs j == i + diag_offset: one block of the MMD's kernel-matrix sums (the multi-GPU
     building block; the matrix is never materialised).  Returns a float64 device scalar, and with
@@ -377,12 +379,12 @@ def kernel_sum(a, b, alphas, dist_eps, exclude_diag=False, diag_offset=0, colsum
         cs = torch.empty(na, dtype=torch.float64, device=dev) if colsum else None
         N.check(N.lib().lvae_kernel_sum_f32(N.ptr(a), N.ptr(b), na, nb, D, arr, nalpha, float(dist_eps),
                                             int(bool(exclude_diag)), int(diag_offset), int(bool(symmetric)),
-                                            N.ptr(total),
+                                            int(path), N.ptr(total),
                                             N.ptr(cs), N.ptr(ws), nbytes.value, N.stream_ptr(dev)))
     return (total[0], cs) if colsum else total[0]
 
 
-def mmd_permutation_sums(cols, col_offset, pooled, labels, alphas, dist_eps, symmetric=None):
+def mmd_permutation_sums(cols, col_offset, pooled, labels, alphas, dist_eps, symmetric=None, path=N.PATH_AUTO):
     """Label-permutation sums of the pooled kernel matrix for the columns this caller owns
     (lvae_mmd_perm_f32): returns (q [P], lr [P], T) as float64 device tensors.  ``labels`` is a [P, n]
     uint8 device tensor (non-zero: element belongs to sample 1 under that labeling); any P (the C entry
@@ -412,7 +414,7 @@ def mmd_permutation_sums(cols, col_offset, pooled, labels, alphas, dist_eps, sym
             pp = lab.shape[0]
             out = torch.empty(2 * pp + 1, dtype=torch.float64, device=dev)
             N.check(N.lib().lvae_mmd_perm_f32(N.ptr(cols), nc, int(col_offset), N.ptr(pooled), n, D, N.ptr(lab),
-                                              pp, arr, nalpha, float(dist_eps), int(bool(symmetric)),
+                                              pp, arr, nalpha, float(dist_eps), int(bool(symmetric)), int(path),
                                               N.ptr(out), N.ptr(ws), nbytes.value, N.stream_ptr(dev)))
             q[p0:p0 + pp] = out[:pp]
             lr[p0:p0 + pp] = out[pp:2 * pp]
@@ -422,13 +424,18 @@ def mmd_permutation_sums(cols, col_offset, pooled, labels, alphas, dist_eps, sym
 
 def permutation_labels(n1, n2, n_permutations, device, generator=None):
     """[1 + n_permutations, n1 + n2] uint8: row 0 is the observed labeling (first n1 elements in sample
-    1), the others are uniformly random relabelings with exactly n1 ones."""
+    1), the others are uniformly random relabelings with exactly n1 ones.  All relabelings of a chunk come from ONE
+    keyed sort of a [rows, n] matrix of float64 uniforms (the n1 smallest keys of a row carry the ones) instead of one
+    sort per labeling: at n = 524,288, P = 100 a single segmented sort, 1,900 launches fewer."""
     n = n1 + n2
     labels = torch.zeros(1 + n_permutations, n, dtype=torch.uint8, device=device)
     labels[0, :n1] = 1
-    for p in range(n_permutations):
-        perm = torch.randperm(n, device=device, generator=generator)
-        labels[1 + p, perm[:n1]] = 1
+    rows = max(1, min(n_permutations, (1 << 26) // max(n, 1)))      # <= 2^26 keys (0.5 GB of float64) per sort
+    for p0 in range(0, n_permutations, rows):
+        r = min(rows, n_permutations - p0)
+        keys = torch.rand(r, n, dtype=torch.float64, device=device, generator=generator)
+        first = keys.argsort(dim=1)[:, :n1]
+        labels[1 + p0:1 + p0 + r].scatter_(1, first, 1)
     return labels
 
 
@@ -441,7 +448,7 @@ def permutation_statistics(q, lr, tot, n1, n2):
 
 
 def mmd_permutation_test(sample_1, sample_2, alphas, n_permutations=1000, dist_eps=1e-5, labels=None,
-                         generator=None):
+                         generator=None, path=N.PATH_AUTO):
     """Two-sample permutation test on the unbiased Gaussian-kernel MMD (torch_two_sample
     MMDStatistic.pval restated without the n x n matrix; PARITY UNPINNED).  Returns a dict: ``statistic``
     (observed), ``statistics`` [n_permutations] (float64, one per relabeling) and ``pval`` = fraction of
@@ -452,7 +459,7 @@ def mmd_permutation_test(sample_1, sample_2, alphas, n_permutations=1000, dist_e
     pooled = torch.cat((s1, s2), 0).contiguous()
     if labels is None:
         labels = permutation_labels(n1, n2, n_permutations, pooled.device, generator)
-    q, lr, tot = mmd_permutation_sums(pooled, 0, pooled, labels, alphas, dist_eps)
+    q, lr, tot = mmd_permutation_sums(pooled, 0, pooled, labels, alphas, dist_eps, path=path)
     stats = permutation_statistics(q, lr, tot, n1, n2)
     return {"statistic": stats[0], "statistics": stats[1:], "pval": (stats[1:] >= stats[0]).double().mean()}
 

@@ -5,7 +5,8 @@ PARITY UNPINNED: josipd/torch-two-sample is an un-vendored submodule with no pin
 (.gitmodules:4-6); this follows its published algorithm -- pooled Euclidean distances
 sqrt(1e-5 + |a.a + b.b - 2 a.b|), kernel sum_alpha exp(-alpha d^2), unbiased statistic with the
 diagonals removed.  ``pval`` (never called by the reference) runs the permutation test from the samples
-of the last call through the fused kernels; an arbitrary kernel matrix is not accepted.
+of the last call through the fused kernels; the only ``distances`` argument it accepts is the matrix that call
+returned (``ret_matrix=True``) -- any other matrix raises, since it would not be the one the result comes from.
 """
 import torch
 
@@ -27,11 +28,13 @@ class MMDStatistic:
         if sample_1.shape[0] != self.n_1 or sample_2.shape[0] != self.n_2:
             raise ValueError("sample sizes differ from the ones the statistic was built for")
         self._last = (sample_1, sample_2, list(alphas))
+        self._last_matrix = None
         out = E.mmd_rbf(sample_1, sample_2, list(alphas), PDIST_EPS, unbiased=True)
         mmd = out[0].float()
         if ret_matrix:
             s12 = torch.cat((N.as_f32(sample_1, "sample_1"), N.as_f32(sample_2, "sample_2")), 0)
-            return mmd, E._kernel_matrix(s12, s12, list(alphas), PDIST_EPS)
+            self._last_matrix = E._kernel_matrix(s12, s12, list(alphas), PDIST_EPS)
+            return mmd, self._last_matrix
         return mmd
 
     def pval(self, distances=None, n_permutations=1000, generator=None):
@@ -40,6 +43,15 @@ class MMDStatistic:
         never read, the label sums are regenerated from the samples on the matrix cores)."""
         if getattr(self, "_last", None) is None:
             raise RuntimeError("call the statistic on two samples first")
+        if distances is not None:
+            mine = getattr(self, "_last_matrix", None)
+            same = mine is not None and (distances is mine or (
+                isinstance(distances, torch.Tensor) and distances.shape == mine.shape
+                and distances.data_ptr() == mine.data_ptr()))
+            if not same:
+                raise ValueError("pval(distances): only the kernel matrix returned by the last call with "
+                                 "ret_matrix=True is accepted (the label sums are regenerated from that call's "
+                                 "samples; another matrix would silently be ignored)")
         s1, s2, alphas = self._last
         return float(E.mmd_permutation_test(s1, s2, alphas, n_permutations, PDIST_EPS,
                                             generator=generator)["pval"])

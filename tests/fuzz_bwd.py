@@ -36,8 +36,10 @@ for c in range(cases):
     for mode in ("mfma", None):
         if mode:
             os.environ["LVAE_BWD_PATH"] = mode
+            __import__("lvae._native", fromlist=["reload_env"]).reload_env()    # (switches are read once per process)
         else:
             os.environ.pop("LVAE_BWD_PATH", None)
+            __import__("lvae._native", fromlist=["reload_env"]).reload_env()    # (switches are read once per process)
         got = _our_grads(mu, lv, z, a)
         for name, gg, w in zip(("d_mu", "d_logvar", "d_z"), got, want):
             scale = max(float(w.abs().max()), 1e-30)

@@ -61,9 +61,8 @@ for c in range(cases):
         a64, b64 = z.astype(np.float64), mu.astype(np.float64)
         d2 = 1e-5 + np.abs((a64 ** 2).sum(1)[:, None] + (b64 ** 2).sum(1)[None] - 2 * a64 @ b64.T)
         want = sum(np.exp(-x * d2) for x in al).sum()
-        for mode in (N.MATH_FP32, N.MATH_BF16X3):
-            with N.pair_math(mode):
-                got = float(E.kernel_sum(dev(z), dev(mu), al, 1e-5, False, 0))
+        for mode in (N.PATH_MFMA, N.PATH_MFMA_BF16X3):
+            got = float(E.kernel_sum(dev(z), dev(mu), al, 1e-5, False, 0, path=mode))
             # (d2 comes from the fp32 expansion |a|^2 + |b|^2 - 2ab: its rounding, times alpha, is the floor)
             if not abs(got - want) <= 1e-4 * want + 1e-12:
                 bad += 1

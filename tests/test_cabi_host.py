@@ -61,10 +61,21 @@ def test_argument_validation_and_error_text():
     assert rc == -1
     dummy = ctypes.c_void_p(256)
     arr = (ctypes.c_float * 2)(0.1, -1.0)
-    rc = lib.lvae_mmd_rbf_f32(dummy, dummy, 8, 8, 32, arr, 2, 1e-5, 1, dummy, dummy, 1 << 30, None)
+    rc = lib.lvae_mmd_rbf_f32(dummy, dummy, 8, 8, 32, arr, 2, 1e-5, 1, 0, dummy, dummy, 1 << 30, None)
     assert rc == -1 and b"non-negative" in lib.lvae_last_error()
-    rc = lib.lvae_mmd_rbf_f32(dummy, dummy, 8, 8, 5000, arr, 1, 1e-5, 1, dummy, dummy, 1 << 30, None)
+    rc = lib.lvae_mmd_rbf_f32(dummy, dummy, 8, 8, 5000, arr, 1, 1e-5, 1, 0, dummy, dummy, 1 << 30, None)
     assert rc == -1 and b"D <= 4096" in lib.lvae_last_error()
+    ok = (ctypes.c_float * 2)(0.1, 1.0)
+    # the MMD entry points take their contraction per call: unknown paths and unsupported combinations are refused
+    rc = lib.lvae_mmd_rbf_f32(dummy, dummy, 8, 8, 32, ok, 2, 1e-5, 1, 9, dummy, dummy, 1 << 30, None)
+    assert rc == -1 and b"unknown path" in lib.lvae_last_error()
+    rc = lib.lvae_mmd_rbf_f32(dummy, dummy, 8, 8, 300, ok, 2, 1e-5, 1, 3, dummy, dummy, 1 << 30, None)
+    assert rc == -4 and b"D <= 256" in lib.lvae_last_error()
+    rc = lib.lvae_kernel_sum_f32(dummy, dummy, 8, 8, 200, ok, 2, 1e-5, 0, 0, 0, 3, dummy, None, dummy, 1 << 30, None)
+    assert rc == -4 and b"split-bf16" in lib.lvae_last_error()
+    rc = lib.lvae_mmd_perm_f32(dummy, 8, 0, dummy, 8, 32, dummy, 4, ok, 2, 1e-5, 0, 2, dummy, dummy, 1 << 30, None)
+    assert rc == -4 and b"direct-difference" in lib.lvae_last_error()
+    assert lib.lvae_dev_reload_env() == 0
     # workspace checks: missing / misaligned / too small
     rc = lib.lvae_log_qz_f32(dummy, dummy, dummy, 0, 8, 8, 32, 0.0, 0, 0, 0, dummy, None, None, 0, None)
     assert rc == -2 and b"NULL" in lib.lvae_last_error()

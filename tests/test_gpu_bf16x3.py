@@ -135,9 +135,11 @@ def test_bf16x3_rejects_what_it_does_not_cover():
     mu = torch.zeros(64, 100, device="cuda")
     with pytest.raises(N.LvaeError, match="bf16x3"):
         E.approximate_log_q_z(mu, mu, mu, method="all", prod_marginals=False, reduce_mean=False, path=BX)
-    with pytest.raises(N.LvaeError, match="pair math"):
-        N.set_pair_math(7)
-    assert N.get_pair_math() == N.MATH_FP32
+    x = torch.zeros(64, 200, device="cuda")          # kernel sums: the split-bf16 form stops at D = 128
+    with pytest.raises(N.LvaeError, match="split-bf16"):
+        E.kernel_sum(x, x, [0.5], 1e-5, path=BX)
+    with pytest.raises(N.LvaeError, match="unknown path"):
+        E.kernel_sum(x[:, :32].contiguous(), x[:, :32].contiguous(), [0.5], 1e-5, path=9)
 
 
 def test_bf16x3_mi_bounds_with_excluded_diagonal():
@@ -162,18 +164,19 @@ def test_bf16x3_mi_bounds_with_excluded_diagonal():
     assert abs(glo - lo) <= 1e-4 * abs(lo) and abs(gup - up) <= 1e-4 * abs(up)
 
 
-# ---- the kernel-sum / MMD entry points under lvae_set_pair_math(LVAE_MATH_BF16X3) -------------------------
-# The same tests as for the fp32 contraction (same oracle, same tolerances), run with the process-wide mode set.
+# ---- the kernel-sum / MMD entry points on the gated split-bf16 form ------------------------------------------
+# The same tests as for the fp32 contraction (same oracle, same tolerances), run with LVAE_PATH_AUTO's size threshold
+# for the split-bf16 kernel sums lowered to zero (LVAE_MMD_BX_MIN_PAIRS, a development switch): every call then takes the
+# gated form -- both contractions prepared and launched, the device-side test picks the split-bf16 kernel.
 import test_gpu_misc as TM     # noqa: E402
 
 
 @pytest.fixture
-def bf16x3_math():
+def bf16x3_math(lvae_env):
     from lvae import _native as N
-    with N.pair_math(N.MATH_BF16X3):
-        assert N.get_pair_math() == N.MATH_BF16X3
-        yield
-    assert N.get_pair_math() == N.MATH_FP32
+    lvae_env.set("LVAE_MMD_BX_MIN_PAIRS", "0")
+    yield
+    lvae_env.unset("LVAE_MMD_BX_MIN_PAIRS")
 
 
 @pytest.mark.parametrize("case", ["n256", "n100_d64"])
@@ -202,12 +205,49 @@ def test_bf16x3_mmd_full_size_properties(bf16x3_math):
 
 def test_bf16x3_mmd_is_a_different_kernel_with_the_same_answer():
     from lvae import _native as N
-    from lvae.two_sample import MMDStatistic
+    from lvae import estimators as E
     g = torch.Generator(device="cuda").manual_seed(4)
     x = torch.randn(8192, 32, device="cuda", generator=g)
     y = torch.randn(8192, 32, device="cuda", generator=g) * 1.05
     alphas = [0.1 * i for i in range(15)]
-    a = float(MMDStatistic(8192, 8192)(x, y, alphas))
-    with N.pair_math(N.MATH_BF16X3):
-        b = float(MMDStatistic(8192, 8192)(x, y, alphas))
+    a = float(E.mmd_rbf(x, y, alphas, 1e-5, True, path=N.PATH_MFMA)[0])
+    b = float(E.mmd_rbf(x, y, alphas, 1e-5, True, path=BX)[0])
     assert abs(a - b) <= 2e-6 * 15
+    assert a != b or True       # (different kernels; equality to the last bit is neither expected nor required)
+
+
+def test_auto_kernel_sums_gate(lvae_env):
+    """LVAE_PATH_AUTO on the kernel sums: above the size threshold both contractions are launched and a device-side
+    test on the largest squared norm lets one run.  Well-conditioned points: bit-equal to the forced split-bf16
+    path; points far from the origin (alpha_max * 4 max|p|^2 > 2e4): bit-equal to the forced fp32 path; below the
+    threshold: the fp32 path.  Every outcome within the oracle's tolerance that its conditioning allows."""
+    from lvae import _native as N
+    from lvae import estimators as E
+    g = torch.Generator(device="cuda").manual_seed(12)
+    a = torch.randn(700, 32, device="cuda", generator=g)
+    b = torch.randn(900, 32, device="cuda", generator=g)
+    alphas = [0.1 * i for i in range(15)]
+    small = float(E.kernel_sum(a, b, alphas, 1e-5))
+    assert small == float(E.kernel_sum(a, b, alphas, 1e-5, path=N.PATH_MFMA))       # 6.3e5 pairs: below the threshold
+    lvae_env.set("LVAE_MMD_BX_MIN_PAIRS", "0")
+    try:
+        for shift, same_as in ((0.0, BX), (20.0, N.PATH_MFMA)):       # |p|^2 ~ 32 / ~ 12,800: 1.4 * 4 * that <> 2e4
+            aa, bb = a + shift, b + shift
+            got = float(E.kernel_sum(aa, bb, alphas, 1e-5))
+            assert got == float(E.kernel_sum(aa, bb, alphas, 1e-5, path=same_as)), shift
+            want = float(E.kernel_sum(aa, bb, alphas, 1e-5, path=N.PATH_DIRECT))    # exact differences
+            assert abs(got - want) <= (1e-6 if shift == 0.0 else 2e-3) * abs(want), (shift, got, want)
+        # the symmetric walk, the excluded diagonal and the permutation sums take the same gate
+        pooled = torch.cat((a, b), 0).contiguous()
+        got = float(E.kernel_sum(pooled[:704], pooled, alphas, 1e-5, True, 0, symmetric=True))
+        assert got == float(E.kernel_sum(pooled[:704], pooled, alphas, 1e-5, True, 0, symmetric=True, path=BX))
+        labels = E.permutation_labels(700, 900, 9, pooled.device, torch.Generator(device="cuda").manual_seed(1))
+        for shift, same_as in ((0.0, BX), (20.0, N.PATH_MFMA)):
+            pp = pooled + shift
+            q, lr, tot = E.mmd_permutation_sums(pp, 0, pp, labels, alphas, 1e-5)
+            q2, lr2, tot2 = E.mmd_permutation_sums(pp, 0, pp, labels, alphas, 1e-5, path=same_as)
+            assert torch.equal(q, q2) and torch.equal(lr, lr2) and float(tot) == float(tot2), shift
+        with pytest.raises(N.LvaeError, match="direct-difference"):
+            E.mmd_permutation_sums(pooled, 0, pooled, labels, alphas, 1e-5, path=N.PATH_DIRECT)
+    finally:
+        lvae_env.unset("LVAE_MMD_BX_MIN_PAIRS")

@@ -50,17 +50,17 @@ def _problem(seed, M, N, D, sigma_scale=1.0):
 
 @pytest.mark.parametrize("M,N,D", [(2048, 3000, 32), (1500, 2500, 8), (3000, 2048, 48), (2100, 2000, 100),
                                    (2048, 2048, 128), (130, 70, 32)])
-def test_matrix_core_backward_vs_float64_autograd(M, N, D, monkeypatch):
-    monkeypatch.setenv("LVAE_BWD_PATH", "mfma")
+def test_matrix_core_backward_vs_float64_autograd(M, N, D, lvae_env):
+    lvae_env.set("LVAE_BWD_PATH", "mfma")
     mu, lv, z, a = _problem(M + D, M, N, D)
     _check(_our_grads(mu, lv, z, a), _reference_grads(mu, lv, z, a, math.log(N)))
 
 
 @pytest.mark.parametrize("case", ["b32", "ragged_d20", "d64", "n300", "d100", "d128"])
-def test_matrix_core_backward_goldens(case, monkeypatch):
+def test_matrix_core_backward_goldens(case, lvae_env):
     """The reference's own autograd gradients (tests/golden/grad_*.npz), joint term, through the MFMA kernels."""
     from lvae import estimators as E
-    monkeypatch.setenv("LVAE_BWD_PATH", "mfma")
+    lvae_env.set("LVAE_BWD_PATH", "mfma")
     g = load_golden("grad_" + case)
     dev = lambda k, grad=False: torch.from_numpy(np.ascontiguousarray(g[k])).cuda().requires_grad_(grad)
     mu, lv, z = dev("mu", True), dev("logvar", True), dev("z", True)
@@ -111,18 +111,18 @@ def test_analysis_scale_wide_latent_needs_no_pair_matrix():
 
 
 @pytest.mark.parametrize("M,N,D", [(1, 1, 1), (5, 1, 3), (1, 7, 16), (33, 31, 17), (129, 257, 65)])
-def test_matrix_core_backward_ragged_and_tiny_shapes(M, N, D, monkeypatch):
-    monkeypatch.setenv("LVAE_BWD_PATH", "mfma")
+def test_matrix_core_backward_ragged_and_tiny_shapes(M, N, D, lvae_env):
+    lvae_env.set("LVAE_BWD_PATH", "mfma")
     mu, lv, z, a = _problem(100 + M + N + D, M, N, D)
     _check(_our_grads(mu, lv, z, a), _reference_grads(mu, lv, z, a, math.log(N)), tol=2e-5)
 
 
-def test_matrix_core_backward_partial_outputs_through_the_c_abi(monkeypatch):
+def test_matrix_core_backward_partial_outputs_through_the_c_abi(lvae_env):
     """Each output gradient on its own (NULL for the others) equals its entry of the full call: sweep B is skipped
     without d_mu / d_logvar, sweep A always runs (it also yields the weight sums of the renormalisation)."""
     from lvae import _native as N
     from lvae import estimators as E
-    monkeypatch.setenv("LVAE_BWD_PATH", "mfma")
+    lvae_env.set("LVAE_BWD_PATH", "mfma")
     M, Nn, D = 700, 900, 40
     mu, lv, z, a = _problem(77, M, Nn, D)
     lq, _ = E.log_qz_raw(mu, lv, z, math.log(Nn), False)

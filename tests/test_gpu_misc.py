@@ -257,13 +257,13 @@ def test_kernel_sum_blocks(na, nb, D, off):
 
 
 @pytest.mark.parametrize("nsplit", [1, 3, 5, 10, 20])
-def test_permutation_sums_symmetric_walk_for_every_split_length(nsplit, monkeypatch):
+def test_permutation_sums_symmetric_walk_for_every_split_length(nsplit, lvae_env):
     """The upper-triangle walk (weights 0 / 1 / 2 per tile, different for the four waves of a workgroup) against
     the full walk, with the posterior axis cut into ranges of 20, 7, 4, 2 and 1 blocks (LVAE_NSPLIT overrides the
     plan): label sums of tiles below the diagonal must not leak in, whatever the range length."""
     import os
     from lvae import estimators as E
-    monkeypatch.setenv("LVAE_NSPLIT", str(nsplit))
+    lvae_env.set("LVAE_NSPLIT", str(nsplit))
     rng = np.random.default_rng(nsplit)
     n, D, P = 640, 32, 37
     x = dev(rng.standard_normal((n, D)).astype(np.float32))
@@ -309,6 +309,13 @@ def test_mmd_permutation_test_unpinned(n1, n2, D, P):
     st(dev(a), dev(b), alphas)
     pv = st.pval(None, n_permutations=16)
     assert 0.0 <= pv <= 1.0
+    if n1 + n2 <= 700:       # upstream's calling convention: the matrix of THAT call is accepted, any other one refused
+        with pytest.raises(ValueError, match="ret_matrix"):
+            st.pval(torch.zeros(n1 + n2, n1 + n2, device="cuda"), n_permutations=4)
+        _, mat = st(dev(a), dev(b), alphas, ret_matrix=True)
+        assert 0.0 <= st.pval(mat, n_permutations=8) <= 1.0
+        with pytest.raises(ValueError, match="ret_matrix"):
+            st.pval(mat.clone(), n_permutations=4)
     # column-sharded evaluation adds up to the same sums, with the full rows ...
     pooled = torch.cat((dev(a), dev(b)), 0)
     q, lr, tot = E.mmd_permutation_sums(pooled, 0, pooled, labels, alphas, 1e-5)         # symmetric

@@ -33,20 +33,20 @@ def _case(kind, rng, N, M, D):
 
 @pytest.mark.parametrize("kind", ["plain", "far", "peaked", "spread"])
 @pytest.mark.parametrize("D", [32, 16, 64])
-def test_fused_tail_sources(kind, D, monkeypatch):
+def test_fused_tail_sources(kind, D, lvae_env):
     from lvae import distributed as LD
     rng = np.random.default_rng([D, len(kind), ord(kind[0])])      # (fixed per case; str hashes change per process)
     N, M = 700, 450
     mu, lv, z, idx = _case(kind, rng, N, M, D)
     mu_l, lv_l = mu[idx].copy(), lv[idx].copy()            # "own" posterior of every sample
     ref, _ = onp.approximate_log_q_z(mu, lv, z, method="all", prod_marginals=False, reduce_mean=False)
-    monkeypatch.setenv("LVAE_NO_SMALL_PATH", "1")          # the general path at a test-sized problem
+    lvae_env.set("LVAE_NO_SMALL_PATH", "1")          # the general path at a test-sized problem
     out = {}
     for fused in (True, False):
         if fused:
-            monkeypatch.delenv("LVAE_NO_FUSED_TAIL", raising=False)
+            lvae_env.unset("LVAE_NO_FUSED_TAIL")
         else:
-            monkeypatch.setenv("LVAE_NO_FUSED_TAIL", "1")
+            lvae_env.set("LVAE_NO_FUSED_TAIL", "1")
         sums, lq = LD.hip_local_stats(dev(mu), dev(lv), dev(z), dev(mu_l), dev(lv_l), math.log(N), False)
         out[fused] = (sums.cpu().numpy(), lq.cpu().numpy())
     s_f, lq_f = out[True]
@@ -66,7 +66,7 @@ def test_fused_tail_sources(kind, D, monkeypatch):
 
 @pytest.mark.parametrize("kind", ["plain", "far", "peaked", "spread"])
 @pytest.mark.parametrize("pm", [False, True])
-def test_late_merge_of_the_plain_entry_point(kind, pm, monkeypatch):
+def test_late_merge_of_the_plain_entry_point(kind, pm, lvae_env):
     """lvae_log_qz_f32 on the general path: the redo merge and the direct-form merge as ONE launch (the late merge
     alone), bit-equal to the two-launch form, with and without the product of marginals."""
     from lvae import estimators as E
@@ -74,13 +74,13 @@ def test_late_merge_of_the_plain_entry_point(kind, pm, monkeypatch):
     N, M, D = 600, 500, 32
     mu, lv, z, _ = _case(kind, rng, N, M, D)
     ref, refpm = onp.approximate_log_q_z(mu, lv, z, method="all", prod_marginals=True, reduce_mean=False)
-    monkeypatch.setenv("LVAE_NO_SMALL_PATH", "1")
+    lvae_env.set("LVAE_NO_SMALL_PATH", "1")
     out = {}
     for fused in (True, False):
         if fused:
-            monkeypatch.delenv("LVAE_NO_FUSED_TAIL", raising=False)
+            lvae_env.unset("LVAE_NO_FUSED_TAIL")
         else:
-            monkeypatch.setenv("LVAE_NO_FUSED_TAIL", "1")
+            lvae_env.set("LVAE_NO_FUSED_TAIL", "1")
         lq, lqpm = E.approximate_log_q_z(dev(mu), dev(lv), dev(z), method="all", prod_marginals=pm, reduce_mean=False)
         out[fused] = (lq.cpu().numpy(), lqpm.cpu().numpy() if pm else None)
     np.testing.assert_array_equal(out[True][0], out[False][0])

@@ -36,6 +36,7 @@ def run(M, Nn, D, reps=5):
         if path == "valu" and D > 64 and M * Nn > (1 << 28):
             continue
         os.environ["LVAE_BWD_PATH"] = path
+        __import__("lvae._native", fromlist=["reload_env"]).reload_env()    # (switches are read once per process)
         grads = bwd(z, mu, lv, math.log(Nn), lq, a)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

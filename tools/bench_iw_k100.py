@@ -11,7 +11,7 @@ lib = N.lib(); st = N.stream_ptr(eps.device)
 def call():
     N.check(lib.lvae_reparam_iw_f32(N.ptr(mu), N.ptr(lv), N.ptr(eps), N.ptr(lpxz), B, K, D, None, N.ptr(lq), N.ptr(lp), N.ptr(iw), st))
 for cfg in (None, ("0","8"), ("0","4"), ("0","2"), ("1","4")):
-    if cfg: os.environ["LVAE_IW_PIPE"], os.environ["LVAE_IW_U"] = cfg
+    if cfg: os.environ["LVAE_IW_PIPE"], os.environ["LVAE_IW_U"] = cfg; __import__("lvae._native", fromlist=["reload_env"]).reload_env()
     for _ in range(3): call()
     torch.cuda.synchronize(); ts=[]
     for _ in range(15):

@@ -24,6 +24,7 @@ for D in (32, 128):
         row = [f"D={D} sigma x{sc}: estimate {estimate(mu, lv):.3g}"]
         for path in ("mfma", "valu"):
             os.environ["LVAE_BWD_PATH"] = path
+            __import__("lvae._native", fromlist=["reload_env"]).reload_env()    # (switches are read once per process)
             got = _our_grads(mu, lv, z, a)
             row.append(path + " " + " ".join(f"{float((g.double() - w).abs().max() / w.abs().max()):.1e}" for g, w in zip(got, want)))
         print("; ".join(row), flush=True)
@@ -36,6 +37,7 @@ for n in (160, 256, 512, 1024, 2048):
     out = []
     for path in ("mfma", "valu", "auto"):
         os.environ["LVAE_BWD_PATH"] = path
+        __import__("lvae._native", fromlist=["reload_env"]).reload_env()    # (switches are read once per process)
         bwd(z, mu, lv, math.log(n), lq, a)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

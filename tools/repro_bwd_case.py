@@ -22,8 +22,8 @@ for c in range(target + 1):
     print(f"case {c}: M={M} N={N} D={D} sigma x{sig} mu x{mus} far={far} zero={zero}")
     want = _reference_grads(mu, lv, z, a, math.log(N), chunk=64)
     for mode in ("mfma", "valu", None):
-        if mode: os.environ["LVAE_BWD_PATH"] = mode
-        else: os.environ.pop("LVAE_BWD_PATH", None)
+        if mode: os.environ["LVAE_BWD_PATH"] = mode; __import__("lvae._native", fromlist=["reload_env"]).reload_env()
+        else: os.environ.pop("LVAE_BWD_PATH", None); __import__("lvae._native", fromlist=["reload_env"]).reload_env()
         got = _our_grads(mu, lv, z, a)
         errs = []
         for gg, w in zip(got, want):

@@ -22,6 +22,7 @@ for B, K, D in shapes:
         for u in ("8", "4", "2"):
             for pipe in ("1", "0"):
                 os.environ["LVAE_IW_U"], os.environ["LVAE_IW_PIPE"] = u, pipe
+                __import__("lvae._native", fromlist=["reload_env"]).reload_env()    # (switches are read once per process)
                 t = timed(lambda: E.reparam_iw(mu, lv, eps, lpxz, return_z=False))
                 t2 = timed(lambda: E.reparam_iw(mu, lv, eps, lpxz, return_z=True))
                 print(f"B={B} K={K} D={D} U={u} pipe={pipe}: no-z {t:.3f} ms   +z {t2:.3f} ms", flush=True)

@@ -18,6 +18,7 @@ for B, K, D in ((65536, 100, 32), (32768, 200, 32), (16384, 400, 32)):
         for u in ("8", "4", "2"):
             for pipe in ("1", "0"):
                 os.environ["LVAE_IW_TPB"], os.environ["LVAE_IW_U"], os.environ["LVAE_IW_PIPE"] = tpb, u, pipe
+                __import__("lvae._native", fromlist=["reload_env"]).reload_env()    # (switches are read once per process)
                 t0 = timed(lambda: E.reparam_iw(mu, lv, eps, lpxz, return_z=False, return_densities=False))
                 t = timed(lambda: E.reparam_iw(mu, lv, eps, lpxz, return_z=False))
                 t2 = timed(lambda: E.reparam_iw(mu, lv, eps, lpxz, return_z=True))

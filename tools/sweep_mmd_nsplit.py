@@ -14,8 +14,10 @@ stat = TS.MMDStatistic(n, n)
 for ns in splits:
     if ns:
         os.environ["LVAE_NSPLIT"] = str(ns)
+        __import__("lvae._native", fromlist=["reload_env"]).reload_env()    # (switches are read once per process)
     else:
         os.environ.pop("LVAE_NSPLIT", None)
+        __import__("lvae._native", fromlist=["reload_env"]).reload_env()    # (switches are read once per process)
     for _ in range(3):
         v = stat(x, y, alphas)
     torch.cuda.synchronize()

@@ -13,8 +13,10 @@ z = mu + torch.randn(n, D, device="cuda", generator=g) * torch.exp(0.5 * lv)
 for ns in splits:
     if ns:
         os.environ["LVAE_NSPLIT"] = str(ns)
+        __import__("lvae._native", fromlist=["reload_env"]).reload_env()    # (switches are read once per process)
     else:
         os.environ.pop("LVAE_NSPLIT", None)
+        __import__("lvae._native", fromlist=["reload_env"]).reload_env()    # (switches are read once per process)
     out = (ctypes.c_int64 * 8)()
     N.check(N.lib().lvae_plan_info(n, n, D, 0, out))
     for _ in range(5):

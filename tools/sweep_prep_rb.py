@@ -12,6 +12,7 @@ f = lambda: LD.hip_local_stats(mu, lv, z, mu, lv, math.log(n), False)
 for _ in range(10): f()
 for rb in (4, 1, 2, 8, 4):
     os.environ["LVAE_PREP_RB"] = str(rb)
+    __import__("lvae._native", fromlist=["reload_env"]).reload_env()    # (switches are read once per process)
     for _ in range(3): f()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(30): s, _ = f()

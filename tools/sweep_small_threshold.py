@@ -9,6 +9,7 @@ for n in (4096, 5792, 6144, 8192, 12288, 16384):
     out = []
     for thr in ("0", "1e10"):
         os.environ["LVAE_SMALL_PAIRS"] = thr
+        __import__("lvae._native", fromlist=["reload_env"]).reload_env()    # (switches are read once per process)
         f = lambda: LD.hip_local_stats(mu, lv, z, mu, lv, math.log(n), False)
         for _ in range(5): f()
         torch.cuda.synchronize(); t0 = time.perf_counter()
