@@ -12,8 +12,16 @@ Workloads (`--workload`, default by --gpus):
         ranks (STRONG scaling: the total is fixed); D = 32 for the metric, `--d 64` is BASELINE configs[2].
         The default at --gpus > 1.
   weak  N = M = 65,536 * sqrt(gpus): every GPU evaluates 65,536^2 pairs whatever the rank count.
-The one JSON line also carries the other multi-GPU mode as a nested object (`also_measured`), and at --gpus 1
-the single-GPU time of the 1m workload, so that the 1 -> 8 curve of the fixed-size job is on record.
+  mmd   BASELINE configs[3]: Gaussian-kernel MMD permutation test, n1 = n2 = 262,144, D = 32, 100 permutations; both
+        samples sharded by rows over the ranks (fixed total: STRONG scaling) -- all-gather of the samples, every rank
+        evaluates two mirrored column chunks of the upper triangle, all-reduce of 2P + 1 float64 sums.
+  iw    BASELINE configs[4]: IW log-likelihood reduction, 16,384 sentences x K = 1,000 samples, D = 32, sentences
+        sharded over the ranks (fixed total: STRONG scaling), all-gather of the [B_r] results.
+The one JSON line also carries the other multi-GPU modes as nested objects (`also_measured`: the other log q(z) mode and
+the mmd / iw workloads on the same ranks), and at --gpus 1 the single-GPU time of the 1m workload, so that the 1 -> 8
+curve of every fixed-size job is on record whichever workload is the headline.  With --gpus > 1 the line has
+`exchange_phases_ms`: per-rank HIP-event times of the phases of an exchange step (own block, time the compute stream
+waited for the all-gather, rest block, merge + sums, all-reduce), so that "the all-gather is hidden" is a number.
 
 One "step" = one pass of the hot path over one batch of synthetic latents already resident in HBM:
 (N > 1: all-gather of the posterior parameters over RCCL, hidden behind the rank's own block of the pair
@@ -37,8 +45,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters (dense fp32 matrix)
+HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
 BASE_N = 65536
 NORTH_STAR_N = 1048576
+MMD_N = 262144                     # BASELINE configs[3]: n1 = n2
+IW_B = 16384                       # BASELINE configs[4]: sentences
+ALPHAS = [0.1 * i for i in range(15)]      # loss_and_optimisation.py:598
 
 
 def parse_args(argv=None):
@@ -46,9 +58,12 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("auto", "c2", "1m", "weak"), default="auto")
+    ap.add_argument("--workload", choices=("auto", "c2", "1m", "weak", "mmd", "iw"), default="auto")
     ap.add_argument("--d", type=int, default=32, help="latent dimension (32: the metric; 64: BASELINE configs[2])")
-    ap.add_argument("--n", type=int, default=0, help="override N = M (development / tests; not a BASELINE workload)")
+    ap.add_argument("--n", type=int, default=0, help="override N = M (mmd: n1 = n2; iw: sentences) -- development / tests; "
+                                                     "not a BASELINE workload")
+    ap.add_argument("--perms", type=int, default=100, help="mmd: permutations (BASELINE configs[3]: 100)")
+    ap.add_argument("--k", type=int, default=1000, help="iw: samples per sentence (BASELINE configs[4]: 1000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-runs", action="store_true", help="skip the nested secondary measurements")
     return ap.parse_args(argv)
@@ -103,6 +118,18 @@ def resolve_workload(args, world):
     name = args.workload
     if name == "auto":
         name = "c2" if world == 1 else "1m"
+    if name == "mmd":
+        n = ((args.n or MMD_N) // world) * world
+        tag = "BASELINE configs[3]" if (n, args.d, args.perms) == (MMD_N, 32, 100) else "development size of configs[3]"
+        return name, n, "strong" if world > 1 else "none", (
+            f"{tag}: Gaussian-kernel MMD permutation test, n1 = n2 = {n:,}, D = {args.d}, {args.perms} permutations, "
+            f"15 bandwidths; rows sharded over {world} GPU(s), fixed total")
+    if name == "iw":
+        n = ((args.n or IW_B) // world) * world
+        tag = "BASELINE configs[4]" if (n, args.d, args.k) == (IW_B, 32, 1000) else "development size of configs[4]"
+        return name, n, "strong" if world > 1 else "none", (
+            f"{tag}: IW log-likelihood reduction (sampling + log-weight logsumexp), {n:,} sentences x K = {args.k} "
+            f"samples, D = {args.d}; sentences sharded over {world} GPU(s), fixed total")
     if args.n:
         n = (args.n // world) * world
         return "custom", n, "strong", f"custom N = M = {n} (development size, not a BASELINE workload)"
@@ -193,9 +220,11 @@ class Bench:
         from lvae import distributed as LD
         self.LD = LD
         self.local_stats, self.block_kernels = LD.hip_local_stats, LD.HipBlockKernels
+        self.permutation_sums, self.reparam_iw = LD.hip_permutation_sums, LD.hip_reparam_iw
         if self.kernels_mod:
             mod = importlib.import_module(self.kernels_mod)
             self.local_stats, self.block_kernels = mod.local_stats, mod.BlockKernels
+            self.permutation_sums, self.reparam_iw = mod.permutation_sums, mod.reparam_iw
         self.gpu = self.device.type == "cuda"
 
     def sync(self):
@@ -271,6 +300,206 @@ class Bench:
         out = LD.stats_from_sums(last[0], last[2], last[1])
         return {"elapsed": elapsed, "k_ms": k_ms, "k_n": k_n, "out": out, "inputs": (mu, logvar, z), "log_norm": log_norm}
 
+    # ---- kernel-time brackets of liblvae (HIP events on the stream the kernels run on) ----------------------------
+    def _prof_begin(self, n):
+        if not self.gpu:
+            return None
+        import ctypes
+        from lvae import _native as N
+        N.check(N.lib().lvae_profile_begin(n))
+        return (ctypes, N)
+
+    @staticmethod
+    def _prof_end(prof):
+        if not prof:
+            return 0.0, 0
+        ctypes, N = prof
+        a, b = ctypes.c_double(0), ctypes.c_int(0)
+        N.check(N.lib().lvae_profile_end(ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def _max_over_ranks(self, elapsed):
+        if self.world > 1:
+            t = self.torch.tensor([elapsed], dtype=self.torch.float64, device="cpu" if self.rehearsal else self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+    def _gather_phases(self, per_step):
+        """Mean per-phase milliseconds of this rank's instrumented steps -> (list over ranks, max over ranks)."""
+        mine = {}
+        for ph in per_step:
+            for k, v in ph.items():
+                mine[k] = mine.get(k, 0.0) + v / len(per_step)
+        ranks = [mine]
+        if self.world > 1:
+            ranks = [None] * self.world
+            self.dist.all_gather_object(ranks, mine)
+        worst = {k: max(r.get(k, 0.0) for r in ranks) for k in ranks[0]}
+        return ranks, worst
+
+    def exchange_phases(self, n_total, D, steps=3):
+        """Instrumented steps of the overlapped exchange, OUTSIDE the timed region (synchronous all-reduce, stamps on the
+        compute stream), plus the all-gathers alone: what the collective costs when nothing hides it."""
+        torch, dist, LD, world = self.torch, self.dist, self.LD, self.world
+        mu, logvar, z = make_inputs(torch, n_total, D, self.rank, world, self.device)
+        counts = [n_total // world] * world
+        per_step = []
+        for i in range(steps + 1):
+            tl = LD.Timeline(self.device)
+            LD.sharded_latent_sums(mu, logvar, z, method="all", counts=counts, local_stats=self.local_stats,
+                                   block_kernels=self.block_kernels, timeline=tl)
+            ph = tl.phases_ms()
+            if i:                        # (the first one warms the shapes up)
+                per_step.append(ph)
+        alone = []
+        gathered = torch.empty((n_total, D), dtype=mu.dtype, device=mu.device)
+        for i in range(steps + 1):
+            self.fence()
+            tl = LD.Timeline(self.device)
+            tl.mark("start")
+            for src in (mu, logvar):
+                LD._all_gather_into(gathered, src.contiguous(), None)
+            tl.mark("all_gather_alone")
+            if i:
+                alone.append(tl.phases_ms())
+        ranks, worst = self._gather_phases(per_step)
+        _, worst_alone = self._gather_phases(alone)
+        n_r = n_total // world
+        return {"steps": steps, "per_rank": ranks, "max_over_ranks": worst,
+                "all_gather_alone_ms": worst_alone.get("all_gather_alone"),
+                "bytes": {"all_gather_received_per_rank": 2 * n_total * D * 4,
+                          "all_gather_sent_per_rank": 2 * n_r * D * 4, "all_reduce": 5 * 8},
+                "note": "HIP events on the compute stream (rehearsal: host clock); wait_all_gather = time the compute "
+                        "stream sat behind the two all-gathers after its own block was done (hidden when ~0)"}
+
+    # ---- BASELINE configs[3]: MMD permutation test ---------------------------------------------------------------
+    def measure_mmd(self, n_each, D, P, steps, warmup, phase_steps=0):
+        torch, LD, world, rank = self.torch, self.LD, self.world, self.rank
+        from lvae import estimators as E
+        n_r = n_each // world
+        g = torch.Generator(device=self.device).manual_seed(4321 + rank)
+        x = torch.randn(n_r, D, device=self.device, generator=g)
+        y = 0.98 * torch.randn(n_r, D, device=self.device, generator=g) + 0.01
+        # the labelings must be the same on every rank: one seed, drawn by every rank for itself (label generation is
+        # part of a user's call -- timed separately below -- but not of the kernel-sum step)
+        gl = torch.Generator(device=self.device).manual_seed(99)
+        self.sync()
+        t0 = time.perf_counter()
+        labels = E.permutation_labels(n_each, n_each, P, self.device, gl)
+        self.sync()
+        t_labels = time.perf_counter() - t0
+        counts = ([n_r] * world, [n_r] * world)
+
+        def step(tl=None):
+            if world > 1:
+                return LD.sharded_mmd_permutation_test(x, y, ALPHAS, labels, group=None, counts=counts,
+                                                       permutation_sums=self.permutation_sums, timeline=tl)
+            pooled = torch.cat((x, y), 0).contiguous()
+            q, lr, tot = self.permutation_sums(pooled, 0, pooled, labels, ALPHAS, 1e-5, True)
+            stats = E.permutation_statistics(q, lr, tot, n_each, n_each)
+            return {"statistic": stats[0], "statistics": stats[1:], "pval": (stats[1:] >= stats[0]).double().mean()}
+
+        for _ in range(warmup):
+            step()
+        self.fence()
+        prof = self._prof_begin(4 * steps)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        self.fence()
+        elapsed = self._max_over_ranks(time.perf_counter() - t0)
+        k_ms, k_n = self._prof_end(prof)
+        phases = None
+        if phase_steps and world > 1:
+            per = []
+            for _ in range(phase_steps):
+                tl = LD.Timeline(self.device)
+                step(tl)
+                per.append(tl.phases_ms())
+            ranks, worst = self._gather_phases(per)
+            phases = {"steps": phase_steps, "per_rank": ranks, "max_over_ranks": worst,
+                      "bytes": {"all_gather_received_per_rank": 2 * n_each * D * 4, "all_reduce": (2 * (P + 1) + 1) * 8}}
+        return {"elapsed": elapsed, "k_ms": k_ms, "k_n": k_n, "labels_s": t_labels, "phases": phases,
+                "statistic": float(out["statistic"]), "pval": float(out["pval"])}
+
+    def mmd_record(self, m, n_each, D, P, steps):
+        n = 2.0 * n_each
+        entries = n * n
+        # SURVEY 8(d) prices an evaluated entry at 2 D flop (distance) + 2 (P + 1) flop (Y = K S, observed labeling
+        # included) and the symmetric matrix at half its entries, against the fp32 MFMA peak
+        flop_rank = 0.5 * entries * (2.0 * D + 2.0 * (P + 1)) / self.world
+        k_avg = m["k_ms"] / steps if m["k_n"] else None
+        achieved = flop_rank / (k_avg * 1e-3) / 1e12 if k_avg else None
+        rec = {"value": entries * steps / m["elapsed"], "unit": "pooled-entries/s", "ms_per_step": m["elapsed"] / steps * 1e3,
+               "steps": steps, "n1": n_each, "n2": n_each, "D": D, "permutations": P,
+               "ms_label_generation": m["labels_s"] * 1e3,
+               "ms_per_step_with_label_generation": (m["elapsed"] / steps + m["labels_s"]) * 1e3,
+               "statistic": m["statistic"], "pval": m["pval"],
+               "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": achieved / FP32_MFMA_PEAK_TFLOPS if achieved else None, "traffic": None,
+                            "kernel": "pair_lse_mfma_kernel<.., PERM> (LVAE_PATH_AUTO: split-bf16 distance + bf16 label "
+                                      "MFMAs; priced with SURVEY 8(d)'s fp32 flop count, so > 1 is possible)",
+                            "kernel_ms_avg": k_avg, "launches": m["k_n"], "flops_per_step_per_rank": flop_rank},
+               "note": "parity unpinned (torch-two-sample absent)"}
+        if m["phases"]:
+            rec["exchange_phases_ms"] = m["phases"]
+        return rec
+
+    # ---- BASELINE configs[4]: IW log-likelihood reduction ----------------------------------------------------------
+    def measure_iw(self, B, K, D, steps, warmup, phase_steps=0):
+        torch, LD, world, rank = self.torch, self.LD, self.world, self.rank
+        B_r = B // world
+        g = torch.Generator(device=self.device).manual_seed(777 + rank)
+        mu = torch.randn(B_r, D, device=self.device, generator=g)
+        lv = 0.5 * torch.randn(B_r, D, device=self.device, generator=g) - 1.0
+        eps = torch.randn(B_r, K, D, device=self.device, generator=g)
+        lpxz = 5.0 * torch.randn(B_r, K, device=self.device, generator=g) - 100.0
+        counts = [B_r] * world
+
+        def step(tl=None):
+            if world > 1:
+                return LD.sharded_iw_log_p_x(mu, lv, eps, lpxz, counts=counts, reparam_iw=self.reparam_iw, timeline=tl)
+            return self.reparam_iw(mu, lv, eps, lpxz)
+
+        for _ in range(warmup):
+            step()
+        self.fence()
+        prof = self._prof_begin(2 * steps)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        self.fence()
+        elapsed = self._max_over_ranks(time.perf_counter() - t0)
+        k_ms, k_n = self._prof_end(prof)
+        phases = None
+        if phase_steps and world > 1:
+            per = []
+            for _ in range(phase_steps):
+                tl = LD.Timeline(self.device)
+                step(tl)
+                per.append(tl.phases_ms())
+            ranks, worst = self._gather_phases(per)
+            phases = {"steps": phase_steps, "per_rank": ranks, "max_over_ranks": worst,
+                      "bytes": {"all_gather_received_per_rank": B * 4}}
+        return {"elapsed": elapsed, "k_ms": k_ms, "k_n": k_n, "phases": phases,
+                "iw_ll_mean": float(out.double().mean()), "rows_out": int(out.numel())}
+
+    def iw_record(self, m, B, K, D, steps):
+        units = float(B) * K
+        bytes_rank = units * (4 * D + 4) / self.world          # SURVEY 8(d): eps + log p(x|z) read per (sentence, sample)
+        k_avg = m["k_ms"] / steps if m["k_n"] else None
+        achieved = bytes_rank / (k_avg * 1e-3) / 1e9 if k_avg else None
+        rec = {"value": units * steps / m["elapsed"], "unit": "(sentence,sample)/s", "ms_per_step": m["elapsed"] / steps * 1e3,
+               "steps": steps, "B": B, "K": K, "D": D, "iw_ll_mean": m["iw_ll_mean"], "gathered_rows": m["rows_out"],
+               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": None,
+                            "kernel": "sample_iw_kernel (reduction only: eps and log p(x|z) in, iw_ll out)",
+                            "kernel_ms_avg": k_avg, "launches": m["k_n"], "bytes_per_step_per_rank": bytes_rank}}
+        if m["phases"]:
+            rec["exchange_phases_ms"] = m["phases"]
+        return rec
+
     def summary(self, m, n_total, D, steps):
         """value / ms_per_step / roofline numbers of one measurement."""
         pairs_total = float(n_total) * float(n_total)
@@ -282,61 +511,94 @@ class Bench:
                 "k_avg_ms": k_avg_ms, "achieved": achieved,
                 "pct_of_peak": value * 4 * D / (self.world * FP32_MFMA_PEAK_TFLOPS * 1e12) * 100.0}
 
-    def other_configs(self):
-        """BASELINE configs[3] and configs[4] on this GPU, timed after the headline measurement and nested in the same
-        line (side records: the headline `value` never depends on them; an error is recorded as text)."""
-        torch = self.torch
-        from lvae import estimators as E
+    def side_configs(self, D):
+        """BASELINE configs[3] and configs[4] on these ranks, timed after the headline measurement and nested in the same
+        line (side records: the headline `value` never depends on them; an error is recorded as text).  Collective:
+        every rank takes part."""
         out = {}
-
-        def timed(fn, reps):
-            fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                r = fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / reps, r
-
-        try:        # configs[4]: IW reduction, K = 1,000 samples x 16,384 sentences, D = 32 (HBM-bound)
-            B, K, D = 16384, 1000, 32
-            g = torch.Generator(device=self.device).manual_seed(7)
-            mu = torch.randn(B, D, device=self.device, generator=g)
-            lv = 0.5 * torch.randn(B, D, device=self.device, generator=g) - 1.0
-            eps = torch.randn(B, K, D, device=self.device, generator=g)
-            lpxz = 5.0 * torch.randn(B, K, device=self.device, generator=g) - 100.0
-            t_red, r = timed(lambda: E.reparam_iw(mu, lv, eps, lpxz, return_z=False, return_densities=False), 20)
-            t_den, _ = timed(lambda: E.reparam_iw(mu, lv, eps, lpxz, return_z=False), 20)
-            by = B * K * (4 * D + 4)
-            out["configs4_iw"] = {"B": B, "K": K, "D": D, "ms_reduction_only": t_red * 1e3, "GBps_reduction_only": by / t_red / 1e9,
-                                  "frac_of_8TBps": by / t_red / 8e12, "ms_with_density_matrices": t_den * 1e3,
-                                  "unit_rate": B * K / t_red, "unit": "(sentence, sample)/s",
-                                  "iw_ll_mean": float(r["iw_ll"].double().mean())}
-            del eps, lpxz, r
-        except Exception as e:
-            out["configs4_iw"] = {"error": repr(e)}
-        try:        # configs[3]: MMD permutation test, n1 = n2 = 262,144, D = 32, 100 permutations (one GPU)
-            n, D, P = 262144, 32, 100
-            g = torch.Generator(device=self.device).manual_seed(11)
-            x = torch.randn(n, D, device=self.device, generator=g)
-            y = 0.98 * torch.randn(n, D, device=self.device, generator=g) + 0.01
-            alphas = [0.1 * i for i in range(15)]
-            labels = E.permutation_labels(n, n, P, self.device, g)
-            t_perm, r = timed(lambda: E.mmd_permutation_test(x, y, alphas, labels=labels), 2)
-            t_stat, _ = timed(lambda: E.mmd_rbf(x, y, alphas, 1e-5, unbiased=True), 2)
-            nn = 2.0 * n
-            out["configs3_mmd_perm"] = {"n1": n, "n2": n, "D": D, "permutations": P, "ms": t_perm * 1e3,
-                                        "ms_statistic_alone": t_stat * 1e3, "pooled_entries_per_s": nn * nn / t_perm,
-                                        "statistic": float(r["statistic"]), "pval": float(r["pval"]),
-                                        "note": "parity unpinned (torch-two-sample absent); fp32 mode"}
-        except Exception as e:
-            out["configs3_mmd_perm"] = {"error": repr(e)}
+        fail = 0
+        for key, fn in (("configs4_iw", lambda: self.iw_record(self.measure_iw(IW_B, 1000, D, 20, 2, 2), IW_B, 1000, D, 20)),
+                        ("configs3_mmd_perm", lambda: self.mmd_record(self.measure_mmd(MMD_N, D, 100, 2, 1, 1), MMD_N, D, 100, 2))):
+            try:
+                out[key] = fn()
+            except Exception as e:                 # noqa: BLE001 -- a side record must never take the headline down
+                out[key] = {"error": repr(e)}
+                fail = 1
+            if self.world > 1:                     # a rank that failed alone would leave the others inside a collective:
+                t = self.torch.tensor([fail], dtype=self.torch.int32, device="cpu" if self.rehearsal else self.device)
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+                if int(t.item()):                  # stop the side runs on every rank together
+                    out.setdefault(key, {"error": "another rank failed"})
+                    break
+        if self.world == 1 and "configs4_iw" in out and "error" not in out["configs4_iw"]:
+            # one GPU: the form that also writes the two [B,K] density matrices, next to the reduction-only one
+            try:
+                from lvae import estimators as E
+                torch = self.torch
+                g = torch.Generator(device=self.device).manual_seed(7)
+                mu = torch.randn(IW_B, D, device=self.device, generator=g)
+                lv = 0.5 * torch.randn(IW_B, D, device=self.device, generator=g) - 1.0
+                eps = torch.randn(IW_B, 1000, D, device=self.device, generator=g)
+                lpxz = 5.0 * torch.randn(IW_B, 1000, device=self.device, generator=g) - 100.0
+                for _ in range(3):
+                    E.reparam_iw(mu, lv, eps, lpxz, return_z=False)
+                self.sync()
+                prof = self._prof_begin(40)
+                for _ in range(20):
+                    E.reparam_iw(mu, lv, eps, lpxz, return_z=False)
+                self.sync()
+                k_ms, k_n = self._prof_end(prof)
+                by = IW_B * 1000 * (4 * D + 4 + 8)
+                out["configs4_iw"]["with_density_matrices"] = {
+                    "kernel_ms_avg": k_ms / max(k_n, 1), "GBps": by / (k_ms / max(k_n, 1) * 1e-3) / 1e9,
+                    "frac_of_8TBps": by / (k_ms / max(k_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "bytes_per_unit": 4 * D + 4 + 8}
+            except Exception as e:                 # noqa: BLE001
+                out["configs4_iw"]["with_density_matrices"] = {"error": repr(e)}
         return out
+
+    def run_side_headline(self, name, n_total, scaling, desc):
+        """`--workload mmd` / `--workload iw`: BASELINE configs[3] / configs[4] as the headline of the line."""
+        args, world, rank = self.args, self.world, self.rank
+        D = args.d
+        if name == "mmd":
+            m = self.measure_mmd(n_total, D, args.perms, args.steps, args.warmup, 2)
+            rec = self.mmd_record(m, n_total, D, args.perms, args.steps)
+            metric = "MMD permutation test: pooled kernel-matrix entries/sec"
+            cfg = {"workload": desc, "name": name, "n1": n_total, "n2": n_total, "D": D, "permutations": args.perms,
+                   "rows_per_gpu": n_total // world,
+                   "parallelism": f"rows of both samples sharded x{world}, all-gather(x, y) + all-reduce(2P+1 sums)",
+                   "exchange": ("all-gather of both samples = %.1f MB received per rank; all-reduce of %d float64"
+                                % (2 * n_total * D * 4 / 1e6, 2 * (args.perms + 1) + 1)) if world > 1 else "none"}
+        else:
+            m = self.measure_iw(n_total, args.k, D, args.steps, args.warmup, 2)
+            rec = self.iw_record(m, n_total, args.k, D, args.steps)
+            metric = "IW log-likelihood reduction: (sentence, sample)-evals/sec"
+            cfg = {"workload": desc, "name": name, "B": n_total, "K": args.k, "D": D, "sentences_per_gpu": n_total // world,
+                   "parallelism": f"sentences sharded x{world}, all-gather of the [B_r] results",
+                   "exchange": ("all-gather of %d float32 = %.1f KB received per rank" % (n_total, n_total * 4 / 1e3))
+                   if world > 1 else "none"}
+        if rank == 0:
+            line = {"metric": metric, "value": rec["value"], "unit": rec["unit"], "n_gpus": world, "steps": args.steps,
+                    "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": scaling,
+                    "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg, "roofline": rec["roofline"],
+                    "results": {k: rec[k] for k in ("statistic", "pval", "iw_ll_mean", "gathered_rows",
+                                                    "ms_label_generation", "ms_per_step_with_label_generation") if k in rec}}
+            if "exchange_phases_ms" in rec:
+                line["exchange_phases_ms"] = rec["exchange_phases_ms"]
+            if self.rehearsal:
+                line["rehearsal"] = "several ranks on one device / injected per-rank compute: the numbers mean nothing"
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
 
     def run(self):
         args, world, rank, torch = self.args, self.world, self.rank, self.torch
         D = args.d
         name, n_total, scaling, desc = resolve_workload(args, world)
+        if name in ("mmd", "iw"):
+            return self.run_side_headline(name, n_total, scaling, desc)
         long_step = float(n_total) ** 2 / world > 4.0 * BASE_N ** 2
         ramp = 2 if long_step else 10
         m = self.measure(n_total, D, args.steps, args.warmup, ramp)
@@ -360,9 +622,9 @@ class Bench:
                            "N": n_total, "M": n_total, "D": D, "pairs_per_gpu": s["pairs_rank"],
                            "rows_per_gpu": n_r,
                            "parallelism": f"row-sharded x{world}, all-gather(mu,logvar)+all-reduce(sums)",
-                           "exchange": ("all-gather of %d x [%d, %d] fp32 = %.1f MB per rank, overlapped with the "
-                                        "own-posterior block; async all-reduce of 5 float64 sums"
-                                        % (world, n_r, 2 * D, world * n_r * 2 * D * 4 / 1e6)) if world > 1 else "none"},
+                           "exchange": ("two all-gathers (mu, logvar) of %d x [%d, %d] fp32 each = %.1f MB received per "
+                                        "rank, overlapped with the own-posterior block; async all-reduce of 5 float64 "
+                                        "sums (40 B)" % (world, n_r, D, 2 * world * n_r * D * 4 / 1e6)) if world > 1 else "none"},
                 "pct_of_fp32_mfma_peak": s["pct_of_peak"],
                 "roofline": {"bound": "mfma", "achieved": s["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS,
                              "unit": "TFLOP/s",
@@ -389,6 +651,10 @@ class Bench:
                 side[other] = {"N": n2, "value": s2["value"], "unit": "pair-evals/s", "ms_per_step": s2["ms_per_step"],
                                "steps": st2, "scaling": "weak" if other == "weak" else "strong",
                                "pct_of_fp32_mfma_peak": s2["pct_of_peak"], "kernel_ms_avg": s2["k_avg_ms"]}
+                del m2
+                # the other sharded configurations on the same ranks, so that every one of them gets its curve from
+                # the driver's default runs (errors are recorded as text, the headline never depends on them)
+                side.update(self.side_configs(D))
             elif name == "c2" and self.gpu:
                 # the fixed-size multi-GPU job on ONE GPU: the base point of its strong-scaling curve
                 st2 = 2
@@ -401,6 +667,10 @@ class Bench:
                 del m2
             if rank == 0:
                 line["also_measured"] = side
+        if world > 1 and not args.no_side_runs:
+            ph = self.exchange_phases(n_total, D)
+            if rank == 0:
+                line["exchange_phases_ms"] = ph
         if rank == 0 and world == 1 and self.gpu and name == "c2":
             from lvae import _native as N
             mu, logvar, z = m["inputs"]
@@ -431,7 +701,7 @@ class Bench:
             except Exception as e:                       # never lose the headline line over the side measurement
                 line["experimental_bf16x3"] = {"error": repr(e)}
             if not args.no_side_runs and D == 32:
-                line["also_measured"].update(self.other_configs())
+                line["also_measured"].update(self.side_configs(D))
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(torch, mu, logvar, z, log_norm, m["out"]["log_q_z_local"], D)
         if rank == 0:

@@ -103,7 +103,10 @@ int lvae_log_qz_noalloc_f32(const float* z, const float* mu, const float* spread
  * registers) as the other branch.  The weights of a sample are renormalised by their own sum, so the caller's
  * log_qz only has to be good to ~1e-2.  With g_prod_marg the vector-ALU sweeps run.  D > 64 on the vector ALU
  * (g_prod_marg given, or D > 128) reads the joint weights from an explicit N x M matrix of pair densities held
- * in the workspace (M * N <= 2^28, LVAE_ERR_UNSUPPORTED beyond). */
+ * in the workspace (M * N <= 2^28, LVAE_ERR_UNSUPPORTED beyond).  One shape has no second branch: 64 < D <= 128 with
+ * M * N > 2^28 and g_log_qz alone runs on the matrix cores only; if its conditioning estimate exceeds the gate's
+ * limit (2e4: d logvar would be good to 1e-4..2e-4 only) every requested gradient is written as NaN -- a loud
+ * result instead of one silently below the parity bar. */
 int lvae_log_qz_bwd_workspace_bytes(int64_t M, int64_t N, int D, int prod_marginals, int64_t* out_bytes);
 int lvae_log_qz_bwd_f32(const float* z, const float* mu, const float* logvar, int64_t M, int64_t N, int D,
                         float log_norm, const float* log_qz, const float* g_log_qz, const float* g_prod_marg,
@@ -383,8 +386,9 @@ int lvae_ks_2samp_f32(const float* a, int64_t n1, const float* b, int64_t n2, do
 
 /* ---------------------------------------------------------------------------------------------
  * Measurement aid (no counterpart in the reference): HIP events recorded on the caller's stream
- * around the pair kernels of lvae_log_qz_f32 / lvae_log_qz_partial_f32, so a benchmark can time the
- * dominant kernel alone.  lvae_profile_end synchronises on those events.
+ * around the pair kernels of lvae_log_qz_f32 / lvae_log_qz_partial_f32 / lvae_latent_stats_f32, the pair launch of
+ * lvae_mmd_perm_f32 and the kernel of lvae_reparam_iw_f32, so a benchmark can time the dominant kernel
+ * alone.  lvae_profile_end synchronises on those events.
  * ------------------------------------------------------------------------------------------- */
 int lvae_profile_begin(int max_launches);
 int lvae_profile_end(double* total_ms, int* launches);

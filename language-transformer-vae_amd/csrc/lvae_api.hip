@@ -131,7 +131,8 @@ int lvae_launch_grad_wide(const float* z, const float* dparams, const float* P, 
                           const PairHeader* gate_hdr = nullptr, float cond_limit = 0.f);
 int lvae_launch_bwd_mfma(const BwdMfmaLayout& L, void* ws, const float* z, const float* mu, const float* logvar,
                          int64_t M, int64_t N, int D, float log_norm, const float* log_qz, const float* g,
-                         PairHeader* hdr, float cond_limit, float* d_z, float* d_mu, float* d_logvar, hipStream_t st);
+                         PairHeader* hdr, float cond_limit, float* d_z, float* d_mu, float* d_logvar, hipStream_t st,
+                         float poison_limit = -1.f);
 BwdMfmaLayout lvae_bwd_mfma_layout(int64_t M, int64_t N, int D);
 int lvae_launch_ksum_wide(const float* a, const float* b, int64_t na, int64_t nb, int D, const PairHeader* hdr,
                           bool excl, int64_t excl_offset, int nsplit, int64_t cpad, double* partial,
@@ -791,8 +792,12 @@ extern "C" int lvae_log_qz_bwd_f32(const float* z, const float* mu, const float*
     if (use_mfma) {
         rc = clear_and_colsum(mu, N, D, hdr, sizeof(PairHeader), st);
         if (rc) return rc;
+        // (64 < D <= 128 beyond 2^28 pairs: the vector-ALU form cannot serve the shape, so there is no branch for an
+        //  estimate past the limit -- the gradients then come out as NaN rather than silently below the 1e-4 bar;
+        //  LVAE_BWD_PATH=mfma, a test switch, runs it ungated and unpoisoned)
+        const float poison = (!use_valu && forced != 2) ? LVAE_BWD_COND_LIMIT : -1.0f;
         rc = lvae_launch_bwd_mfma(g.mf, base + g.off_mfma, z, mu, logvar, M, N, D, log_norm, log_qz, g_log_qz, hdr,
-                                  use_valu ? LVAE_BWD_COND_LIMIT : -1.0f, d_z, d_mu, d_logvar, st);
+                                  use_valu ? LVAE_BWD_COND_LIMIT : -1.0f, d_z, d_mu, d_logvar, st, poison);
         if (rc || !use_valu) return rc;
         gate = hdr;
     }
@@ -956,8 +961,11 @@ extern "C" int lvae_reparam_iw_f32(const float* mu, const float* logvar, const f
     if (rc) return rc;
     LVAE_CHECK_ARG(mu && logvar && eps, "mu, logvar and eps must be non-NULL");
     LVAE_CHECK_ARG(z || log_q_z_x || log_p_z || iw_ll, "no output requested");
-    return lvae_launch_sample_iw(true, mu, logvar, eps, log_p_x_z, B, K, D, z, log_q_z_x, log_p_z, iw_ll,
-                                 (hipStream_t)stream);
+    hipEvent_t prof_stop = prof_mark((hipStream_t)stream, nullptr);
+    rc = lvae_launch_sample_iw(true, mu, logvar, eps, log_p_x_z, B, K, D, z, log_q_z_x, log_p_z, iw_ll,
+                               (hipStream_t)stream);
+    if (prof_stop) prof_mark((hipStream_t)stream, prof_stop);
+    return rc;
 }
 
 // ---- the whole training-time tail of encode() for one small batch, one launch each way --------------------------
@@ -1626,6 +1634,7 @@ extern "C" int lvae_mmd_perm_f32(const float* cols, int64_t nc, int64_t col_offs
     pa.C = nc;
     pa.P = P;
     const int epi = ksum_epi(kp);
+    hipEvent_t prof_stop = prof_mark(st, nullptr);
     if (!m.bx) {
         rc = lvae_launch_pair_mfma_perm(p, r.rfrag, r.rbias, r.cop, r.partial, r.hdr, -1.f, 0, col_offset, epi, pa, sym,
                                         r.colnorm, st);
@@ -1639,6 +1648,7 @@ extern "C" int lvae_mmd_perm_f32(const float* cols, int64_t nc, int64_t col_offs
                                             epi, pa, sym, r.colnorm, st);
     }
     if (rc) return rc;
+    if (prof_stop) prof_mark(st, prof_stop);
     return lvae_launch_perm_lr((const double*)r.partial, diag_partial, p.nsplit, p.cpad, nc, labels, n, col_offset,
                                P, sym, qperm, out, st);
 }

@@ -316,10 +316,16 @@ bwd_rescale_g_kernel(const float* __restrict__ wsum, int nsplit, int64_t cpad, c
 __global__ void __launch_bounds__(256)
 bwd_merge_dz_kernel(const float* __restrict__ partial, int nsplit, int64_t cpad, int DP, const float* __restrict__ z,
                     const float* __restrict__ g, int64_t M, int64_t N, int D, const PairHeader* __restrict__ hdr,
-                    float cond_limit, float* __restrict__ d_z) {
+                    float cond_limit, float poison_limit, float* __restrict__ d_z) {
     if (cond_limit >= 0.f && __uint_as_float(hdr->cond_bits) > cond_limit) return;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= M * D) return;
+    // no other branch behind this call and the estimate is past the limit: the result would be below the parity bar
+    // without anybody noticing -- make it NaN instead (lvae.h, lvae_log_qz_bwd_f32)
+    if (poison_limit >= 0.f && __uint_as_float(hdr->cond_bits) > poison_limit) {
+        d_z[idx] = __builtin_nanf("");
+        return;
+    }
     const int64_t i = idx / D;
     const int d = (int)(idx - i * D);
     float s1 = 0.f, s2 = 0.f;
@@ -335,11 +341,16 @@ bwd_merge_dz_kernel(const float* __restrict__ partial, int nsplit, int64_t cpad,
 __global__ void __launch_bounds__(256)
 bwd_merge_dp_kernel(const float* __restrict__ partial, const float* __restrict__ wsum, int nsplit, int64_t cpad, int DP,
                     const float* __restrict__ mu, const float* __restrict__ logvar, int64_t N, int D,
-                    const PairHeader* __restrict__ hdr, float cond_limit, float* __restrict__ d_mu,
+                    const PairHeader* __restrict__ hdr, float cond_limit, float poison_limit, float* __restrict__ d_mu,
                     float* __restrict__ d_logvar) {
     if (cond_limit >= 0.f && __uint_as_float(hdr->cond_bits) > cond_limit) return;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= N * D) return;
+    if (poison_limit >= 0.f && __uint_as_float(hdr->cond_bits) > poison_limit) {
+        if (d_mu) d_mu[idx] = __builtin_nanf("");
+        if (d_logvar) d_logvar[idx] = __builtin_nanf("");
+        return;
+    }
     const int64_t j = idx / D;
     const int d = (int)(idx - j * D);
     float t2 = 0.f, t1 = 0.f, t0 = 0.f;
@@ -413,16 +424,20 @@ static void launch_sweeps(const BwdMfmaLayout& L, char* base, int64_t M, int64_t
 // hdr: zeroed, with the column sums of mu already in it (colsum_kernel).  base: the region lvae_bwd_mfma_layout sizes.
 // cond_limit < 0: unconditional; otherwise everything behind the operand preparation runs iff the conditioning
 // estimate is <= cond_limit (the caller launches the vector-ALU sweeps with the opposite gate).
+// poison_limit >= 0 (with cond_limit < 0: no other branch exists for this shape): the gradients come out as NaN when
+// the estimate exceeds it, instead of silently below the parity bar.
 int lvae_launch_bwd_mfma(const BwdMfmaLayout& L, void* ws, const float* z, const float* mu, const float* logvar,
                          int64_t M, int64_t N, int D, float log_norm, const float* log_qz, const float* g,
-                         PairHeader* hdr, float cond_limit, float* d_z, float* d_mu, float* d_logvar, hipStream_t st) {
+                         PairHeader* hdr, float cond_limit, float* d_z, float* d_mu, float* d_logvar, hipStream_t st,
+                         float poison_limit) {
     if (L.DP == 0) return lvae_set_error(LVAE_ERR_UNSUPPORTED, "the MFMA backward needs D <= 128 (got D=%d)", D);
     char* base = (char*)ws;
     const int64_t nbj = L.cpad_j / 32, nbi = L.cpad_i / 32;
     hipLaunchKernelGGL(bwd_prep_kernel, dim3((unsigned)(nbj + nbi)), dim3(256), 0, st, mu, logvar, N, z, log_qz, log_norm,
                        g, M, D, L.DP, hdr, nbj, (float*)(base + L.off_recj), (float*)(base + L.off_colj),
                        (float*)(base + L.off_cbj), (float*)(base + L.off_reci), (float*)(base + L.off_coli),
-                       (float*)(base + L.off_cbi), (float*)(base + L.off_cgj), cond_limit >= 0.f ? cond_limit : INFINITY);
+                       (float*)(base + L.off_cbi), (float*)(base + L.off_cgj),
+                       cond_limit >= 0.f ? cond_limit : (poison_limit >= 0.f ? poison_limit : INFINITY));
     const bool want_z = d_z != nullptr, want_p = d_mu || d_logvar;
     switch (L.DP) {
         case 16: launch_sweeps<16, 2>(L, base, M, N, g, want_p, hdr, cond_limit, st); break;
@@ -433,11 +448,11 @@ int lvae_launch_bwd_mfma(const BwdMfmaLayout& L, void* ws, const float* z, const
     if (want_z)
         hipLaunchKernelGGL(bwd_merge_dz_kernel, dim3((unsigned)lvae_ceil_div(M * D, 256)), dim3(256), 0, st,
                            (const float*)(base + L.off_pa), L.ns_a, L.cpad_i, L.DP, z, (const float*)(base + L.off_gs), M, N, D, hdr,
-                           cond_limit, d_z);
+                           cond_limit, poison_limit, d_z);
     if (want_p)
         hipLaunchKernelGGL(bwd_merge_dp_kernel, dim3((unsigned)lvae_ceil_div(N * D, 256)), dim3(256), 0, st,
                            (const float*)(base + L.off_pb), (const float*)(base + L.off_w0), L.ns_b, L.cpad_j, L.DP, mu,
-                           logvar, N, D, hdr, cond_limit, d_mu, d_logvar);
+                           logvar, N, D, hdr, cond_limit, poison_limit, d_mu, d_logvar);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
 }

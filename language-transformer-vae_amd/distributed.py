@@ -91,6 +91,12 @@ def hip_local_stats(mu_all, logvar_all, z_local, mu_local, logvar_local, log_nor
     from . import estimators as E
     z, mu, lv = (N.as_f32(t, n) for t, n in ((z_local, "z"), (mu_local, "mu"), (logvar_local, "logvar")))
     dev = z.device
+    if z.dim() != 2 or mu.shape != z.shape or lv.shape != z.shape:
+        raise ValueError(f"local rows must share one [n_r, D] shape: z {tuple(z.shape)}, mu {tuple(mu.shape)}, "
+                         f"logvar {tuple(lv.shape)}")
+    if mu_all.dim() != 2 or mu_all.shape != logvar_all.shape or mu_all.shape[1] != z.shape[1]:
+        raise ValueError(f"gathered posteriors must be [N, D] with the local D: mu_all {tuple(mu_all.shape)}, "
+                         f"logvar_all {tuple(logvar_all.shape)}, z {tuple(z.shape)}")
     if not prod_marginals:
         mu_a, lv_a = N.as_f32(mu_all, "mu"), N.as_f32(logvar_all, "logvar")
         M, D = z.shape
@@ -138,34 +144,82 @@ class HipBlockKernels:
         return sums
 
 
-def overlapped_stats(packed_local, z_local, mu_local, logvar_local, group, log_norm_of, kernels=HipBlockKernels):
+class Timeline:
+    """Per-phase stamps of one exchange step: HIP events on the current stream for GPU tensors (the stream's own
+    clock: what the device did, not when the host queued it), ``time.perf_counter`` for the CPU rehearsal.
+    ``phases_ms()`` synchronises and returns {phase: milliseconds between its stamp and the previous one}."""
+
+    def __init__(self, device):
+        self.cuda = torch.device(device).type == "cuda"
+        self.device = device
+        self.marks = []
+
+    def mark(self, name):
+        if self.cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.device))
+            self.marks.append((name, ev))
+        else:
+            import time
+            self.marks.append((name, time.perf_counter()))
+
+    def phases_ms(self):
+        if self.cuda:
+            torch.cuda.synchronize(self.device)
+        out = {}
+        for (_, a), (name, b) in zip(self.marks[:-1], self.marks[1:]):
+            out[name] = out.get(name, 0.0) + (a.elapsed_time(b) if self.cuda else (b - a) * 1e3)
+        return out
+
+
+def overlapped_stats(mu_local, logvar_local, z_local, group, log_norm_of, kernels=HipBlockKernels, timeline=None):
     """The exchange step with the all-gather hidden behind compute (equal shard sizes, joint density only).
-    The logsumexp over posteriors is order-free, so it is evaluated in two blocks:
-      1. the all-gather of the packed [n_r, 2D] parameters is started asynchronously (RCCL runs it on its own
-         stream; with the host-staged gloo rehearsal of GPU tensors it simply runs first);
+    The logsumexp over posteriors is order-free, so it is evaluated in blocks:
+      1. the all-gathers of mu and logvar ([n_r, D] each -> [world * n_r, D]: two collectives, so that every rank's
+         block AND every range of ranks is a contiguous [rows, D] matrix the kernels read in place) are started
+         asynchronously (RCCL runs them on its own stream; with the host-staged gloo rehearsal of GPU tensors they
+         simply run first);
       2. meanwhile this rank's samples are contracted against its OWN posteriors (1/world of the pairs) into a
          partial logsumexp (lvae_log_qz_partial_f32);
-      3. the current stream waits for the collective; the same samples go against all OTHER posteriors (one
-         contiguous copy of the two ranges around the own shard), and the two partials are merged
-         (lvae_lse_combine_f32).
+      3. the current stream waits for the collectives; the same samples go against the posteriors of the ranks BEFORE
+         this one and of the ranks AFTER it -- two row ranges of the gathered buffers, read where they lie (no
+         copy: the first and the last rank have one range) -- and the partials are merged (lvae_lse_combine_f32).
+    ``timeline`` (a Timeline): stamps after each phase -- own_block, wait_all_gather (how long the compute stream sat
+    behind the collective once its own block was done: ~0 when the all-gather is hidden), rest_block, merge_and_sums.
     Returns (sums [5] float64, log_q_z of the local rows, n_total)."""
     ws, rank = dist.get_world_size(group), dist.get_rank(group)
     n_r, D = mu_local.shape
-    gathered = torch.empty((ws * n_r, 2 * D), dtype=packed_local.dtype, device=packed_local.device)
-    work = None
-    if packed_local.is_cuda and _host_staged(group):
-        _all_gather_into(gathered, packed_local, group)
+    mu_local, logvar_local = mu_local.contiguous(), logvar_local.contiguous()
+    mu_all = torch.empty((ws * n_r, D), dtype=mu_local.dtype, device=mu_local.device)
+    lv_all = torch.empty((ws * n_r, D), dtype=mu_local.dtype, device=mu_local.device)
+    works = []
+    if timeline is not None:
+        timeline.mark("start")
+    if mu_local.is_cuda and _host_staged(group):
+        _all_gather_into(mu_all, mu_local, group)
+        _all_gather_into(lv_all, logvar_local, group)
     else:
-        work = dist.all_gather_into_tensor(gathered, packed_local, group=group, async_op=True)
-    own = kernels.partial(mu_local, logvar_local, z_local)
-    if work is not None:
-        work.wait()                      # GPU: the current stream waits for the collective, the host does not
+        works.append(dist.all_gather_into_tensor(mu_all, mu_local, group=group, async_op=True))
+        works.append(dist.all_gather_into_tensor(lv_all, logvar_local, group=group, async_op=True))
+    acc = kernels.partial(mu_local, logvar_local, z_local)
+    if timeline is not None:
+        timeline.mark("own_block")
+    for w in works:
+        w.wait()                         # GPU: the current stream waits for the collective, the host does not
+    if timeline is not None:
+        timeline.mark("wait_all_gather")
     lo, hi = rank * n_r, (rank + 1) * n_r
-    others = torch.cat([gathered[:lo], gathered[hi:]], dim=0)
     n_total = ws * n_r
-    rest = kernels.partial(others[:, :D].contiguous(), others[:, D:].contiguous(), z_local) if others.shape[0] else None
-    log_q_z = kernels.combine(own, rest, log_norm_of(n_total))
-    return kernels.sums(z_local, mu_local, logvar_local, log_q_z), log_q_z, n_total
+    for a, b in ((0, lo), (hi, n_total)):
+        if b > a:
+            acc = kernels.combine(acc, kernels.partial(mu_all[a:b], lv_all[a:b], z_local), None)
+    if timeline is not None:
+        timeline.mark("rest_block")
+    log_q_z = kernels.combine(acc, None, log_norm_of(n_total))
+    sums = kernels.sums(z_local, mu_local, logvar_local, log_q_z)
+    if timeline is not None:
+        timeline.mark("merge_and_sums")
+    return sums, log_q_z, n_total
 
 
 def sharded_latent_stats(mu_local, logvar_local, z_local, method="all", dataset_size=None,
@@ -203,14 +257,14 @@ def stats_from_sums(sums, n_total, log_q_z_local, prod_marginals=False):
 
 def sharded_latent_sums(mu_local, logvar_local, z_local, method="all", dataset_size=None,
                         prod_marginals=False, group=None, local_stats=hip_local_stats, counts=None,
-                        overlap=None, block_kernels=HipBlockKernels, async_reduce=False):
+                        overlap=None, block_kernels=HipBlockKernels, async_reduce=False, timeline=None):
     """Exchange + per-rank compute + all-reduce of ``sharded_latent_stats`` without its host read: returns
     (sums [5] float64 on the compute device, identical on every rank: sum log q(z), sum log prod-marginals,
     sum log p(z), sum log q(z|x), row count; this rank's log q(z) vector; n_total).  Nothing here waits on
     the host, so consecutive calls queue behind each other on the device.  ``async_reduce``: the compute
     stream does not wait for the final all-reduce either (the next call's kernels start at once); a fourth
-    return value is then the collective's work handle (or None), to be ``wait()``-ed before ``sums`` is read."""
-    packed = torch.cat([mu_local, logvar_local], dim=1).contiguous()
+    return value is then the collective's work handle (or None), to be ``wait()``-ed before ``sums`` is read.
+    ``timeline`` (a Timeline; overlapped exchange only): per-phase stamps, the all-reduce included."""
     if method == "chen":
         assert dataset_size is not None
 
@@ -227,9 +281,10 @@ def sharded_latent_sums(mu_local, logvar_local, z_local, method="all", dataset_s
         if not can_overlap:
             raise ValueError("overlap=True needs the HIP path, equal shard sizes given by `counts`, "
                              "prod_marginals=False and world_size > 1")
-        sums, log_q_z, n_total = overlapped_stats(packed, z_local, mu_local, logvar_local, group, log_norm_of,
-                                                  block_kernels)
+        sums, log_q_z, n_total = overlapped_stats(mu_local, logvar_local, z_local, group, log_norm_of, block_kernels,
+                                                  timeline)
     else:
+        packed = torch.cat([mu_local, logvar_local], dim=1).contiguous()
         gathered, _ = all_gather_rows(packed, group, counts)
         D = mu_local.shape[1]
         mu_all, logvar_all = gathered[:, :D].contiguous(), gathered[:, D:].contiguous()
@@ -238,20 +293,37 @@ def sharded_latent_sums(mu_local, logvar_local, z_local, method="all", dataset_s
                                     prod_marginals)
     sums = sums.to(torch.float64).contiguous()
     work = _all_reduce(sums, dist.ReduceOp.SUM, group, async_op=async_reduce)
+    if timeline is not None and overlap:
+        if work is not None:
+            work.wait()
+        timeline.mark("all_reduce")
     if async_reduce:
         return sums, log_q_z, n_total, work
     return sums, log_q_z, n_total
 
 
-def sharded_iw_log_p_x(mu_local, logvar_local, eps_local, log_p_x_z_local, group=None, gather=True):
+def hip_reparam_iw(mu, logvar, eps, log_p_x_z):
+    """Per-rank compute of sharded_iw_log_p_x on the HIP path: the reduction-only IW kernel -> iw_ll [B_r]."""
+    from . import estimators as E
+    return E.reparam_iw(mu, logvar, eps, log_p_x_z, return_z=False, return_densities=False)["iw_ll"]
+
+
+def sharded_iw_log_p_x(mu_local, logvar_local, eps_local, log_p_x_z_local, group=None, gather=True, counts=None,
+                       reparam_iw=hip_reparam_iw, timeline=None):
     """IW log-likelihood with sentences sharded over ranks (independent per sentence, like the
     DistributedSampler split at dist_iw_...py:86-87); the optional all-gather of the [B_r] results
-    replaces the reference's pickle concatenation (:48-73)."""
-    from . import estimators as E
-    iw = E.reparam_iw(mu_local, logvar_local, eps_local, log_p_x_z_local, return_z=False, return_densities=False)["iw_ll"]
+    replaces the reference's pickle concatenation (:48-73).  ``counts``: sentences per rank if known (saves the size
+    exchange and its host synchronisation); ``timeline``: stamps after the kernel and after the gather."""
+    if timeline is not None:
+        timeline.mark("start")
+    iw = reparam_iw(mu_local, logvar_local, eps_local, log_p_x_z_local)
+    if timeline is not None:
+        timeline.mark("kernel")
     if not gather:
         return iw
-    out, _ = all_gather_rows(iw.reshape(-1, 1), group)
+    out, _ = all_gather_rows(iw.reshape(-1, 1), group, counts)
+    if timeline is not None:
+        timeline.mark("all_gather")
     return out.reshape(-1)
 
 
@@ -314,16 +386,22 @@ def mirrored_chunks(n, world_size, rank, align=32):
 
 
 def sharded_mmd_permutation_test(x_local, y_local, alphas, labels, dist_eps=1e-5, group=None,
-                                 permutation_sums=hip_permutation_sums):
+                                 permutation_sums=hip_permutation_sums, counts=None, timeline=None):
     """MMD permutation test with both samples sharded by rows (samples replicated by
     all-gather, kernel-matrix columns partitioned, all-reduce of the [P, 2] label sums and the total).
     After the gather every rank holds the pooled sample, so the COMPUTE partition is free: each rank
     evaluates two mirrored column chunks of the upper triangle (``mirrored_chunks``), half the work of the
     full matrix and balanced over ranks.
     ``labels``: [P, n1 + n2] uint8, identical on every rank (row 0 = observed labeling: first n1 ones), in
-    POOLED order = all of x (rank order) followed by all of y.  Returns a dict identical on every rank."""
-    x_all, _ = all_gather_rows(x_local.contiguous(), group)
-    y_all, _ = all_gather_rows(y_local.contiguous(), group)
+    POOLED order = all of x (rank order) followed by all of y.  ``counts`` = (rows of x per rank, rows of y per
+    rank) if known (saves the two size exchanges); ``timeline``: stamps after the gathers, the kernels and the
+    all-reduce.  Returns a dict identical on every rank."""
+    if timeline is not None:
+        timeline.mark("start")
+    x_all, _ = all_gather_rows(x_local.contiguous(), group, None if counts is None else counts[0])
+    y_all, _ = all_gather_rows(y_local.contiguous(), group, None if counts is None else counts[1])
+    if timeline is not None:
+        timeline.mark("all_gather")
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     n1, n2 = x_all.shape[0], y_all.shape[0]
     pooled = torch.cat((x_all, y_all), 0).contiguous()
@@ -332,7 +410,11 @@ def sharded_mmd_permutation_test(x_local, y_local, alphas, labels, dist_eps=1e-5
     for lo, hi in mirrored_chunks(n1 + n2, world, rank):
         q, lr, tot = permutation_sums(pooled[lo:hi].contiguous(), lo, pooled, labels, alphas, dist_eps, True)
         sums += torch.cat((q.reshape(-1), lr.reshape(-1), tot.reshape(1))).to(torch.float64)
+    if timeline is not None:
+        timeline.mark("kernels")
     _all_reduce(sums, dist.ReduceOp.SUM, group)
+    if timeline is not None:
+        timeline.mark("all_reduce")
     s = sums.cpu()
     q, lr, tot = s[:P], s[P:2 * P], s[2 * P]
     k12 = lr - q

@@ -278,6 +278,8 @@ class _OracleBlockKernels:
             mm = np.maximum(m, m2)
             s = s * np.exp(m - mm) + s2 * np.exp(m2 - mm)
             m = mm
+        if log_norm is None:             # merged (max, sum) pair, like estimators.lse_combine
+            return torch.from_numpy(m), torch.from_numpy(s)
         return torch.from_numpy(m + np.log(s) - log_norm)
 
     @staticmethod
@@ -352,3 +354,43 @@ def test_overlapped_exchange_matches_plain(world):
     np.testing.assert_allclose(res["lq_over"], res["lq_plain"], rtol=1e-10, atol=1e-10)
     assert abs(res["auto_marginal_kl"] - (res["plain"]["marginal_kl"] - math.log(500))) < 1e-9
     assert res["err"] and "overlap=True needs" in res["err"]
+
+
+def _lse_far_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lvae import distributed as LD
+    rng = np.random.default_rng(40)
+    M = 257
+    # every rank's partials for ALL rows; the maxima of the ranks lie up to ~200 nats apart, row by row in a
+    # different order, so that every rank is the dominant one somewhere and flushed to zero somewhere else
+    maxes = rng.standard_normal((world, M)) * 5.0 + np.array([0.0, -60.0, -200.0])[:world, None] * rng.choice([1.0, -1.0], (1, M))
+    sums = rng.uniform(1.0, 50.0, (world, M))
+    out = LD.combine_partial_lse(torch.from_numpy(maxes[rank]).float(), torch.from_numpy(sums[rank]).float(),
+                                 math.log(1000.0), kernels=_OracleLseKernels)
+    if rank == 0:
+        q.put((out.numpy(), maxes.astype(np.float32).astype(np.float64), sums.astype(np.float32).astype(np.float64)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_combine_partial_lse_with_rank_maxima_far_apart():
+    """The column-sharded merge exchanges float32 sums re-based on the global maximum (lvae_lse_rebase_f32): a rank
+    whose maximum lies > 87 nats below the global one contributes exactly 0, the others round at 2^-24 per add.
+    Against the float64 logsumexp of the same float32 partials: 1e-6."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lse_far_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, maxes, sums = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    gm = maxes.max(0)
+    want = gm + np.log((sums * np.exp(maxes - gm[None])).sum(0)) - math.log(1000.0)
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)

@@ -151,3 +151,26 @@ def test_matrix_core_backward_partial_outputs_through_the_c_abi(lvae_env):
         N.check(N.lib().lvae_log_qz_bwd_f32(N.ptr(z), N.ptr(mu), N.ptr(lv), M, Nn, D, math.log(Nn), N.ptr(lq), N.ptr(a),
                                             None, N.ptr(full[0]), None, None, N.ptr(ws), nbytes.value - 1,
                                             N.stream_ptr(z.device)))
+
+
+def test_wide_latents_beyond_the_vector_alu_envelope_fail_loudly_when_ill_conditioned():
+    """64 < D <= 128 with M * N > 2^28 has no vector-ALU branch (its explicit pair matrix is capped at 2^28 entries), so
+    the matrix-core backward is the only form: well-conditioned posteriors give gradients within the bar of a float64
+    spot check, and an estimate past the gate's limit yields NaN in every requested gradient instead of a silently
+    degraded d logvar (include/lvae.h, lvae_log_qz_bwd_f32)."""
+    M = N = 16400                       # 2.69e8 pairs > 2^28
+    D = 100
+    mu, lv, z, a = _problem(5, M, N, D)
+    got = _our_grads(mu, lv, z, a)
+    assert all(bool(torch.isfinite(t).all()) for t in got)
+    # float64 spot check of d z on a few samples (the full reference would be 2.7e8 x 100 terms on the host path)
+    rows = torch.tensor([0, 777, 8191, 16399], device="cuda")
+    z64 = z[rows].double().requires_grad_(True)
+    dens = (-0.5 * (lv.double()[None] + math.log(2 * math.pi) + (z64[:, None, :] - mu.double()[None]) ** 2
+                    * torch.exp(-lv.double())[None])).sum(2)
+    ((torch.logsumexp(dens, 1) - math.log(N)) * a[rows].double()).sum().backward()
+    scale = float(z64.grad.abs().max())
+    assert float((got[2][rows].double() - z64.grad).abs().max()) <= 1e-4 * scale
+    # posteriors far from their common mean with small sigma: estimate >> 2e4 -> NaN, not a quiet loss of accuracy
+    bad = _our_grads(mu * 40.0, lv - 4.0, z * 40.0, a)
+    assert all(bool(torch.isnan(t).all()) for t in bad)
