@@ -424,6 +424,34 @@ def case_mi_generative(mi, name, seed, K, V, peaked):
     print("wrote mi_generative", name, lower, upper)
 
 
+def case_pareto(seed):
+    """is_pareto_efficient_simple (utils_train.py:416-431).  utils_train does not import here (it pulls transformers
+    4.2.2 internals at module scope), but the function is sixteen self-contained lines of NumPy: its FunctionDef node
+    is taken out of the reference file with `ast` and run as the reference wrote it.  Gain matrices with ties,
+    duplicates, a dominated copy placed BEFORE its dominator, one column, and a single point."""
+    import ast
+    path = os.path.join(REF, "utils_train.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "is_pareto_efficient_simple")
+    ns = {"np": np}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)     # the reference's own function
+    fn = ns["is_pareto_efficient_simple"]
+    rng = np.random.default_rng(seed)
+    out = {}
+    shapes = [(1, 3), (12, 2), (40, 3), (25, 5), (300, 2), (64, 7), (50, 1), (200, 4)]
+    for k, (n, d) in enumerate(shapes):
+        g = np.round(rng.standard_normal((n, d)), 1 if k % 2 == 0 else 3)        # coarse rounding: ties and duplicates
+        if n > 4:
+            g[n // 2] = g[0]                     # exact duplicate of an earlier point
+            g[1] = g[n - 1] - 0.5                # dominated point ahead of its dominator
+            g[n // 3, 0] = g[n // 3 + 1, 0]      # tie in one coordinate
+        out[f"gains_{k}"] = g.astype(np.float64)
+        out[f"efficient_{k}"] = fn(g.copy())
+    out["n_cases"] = np.array(len(shapes))
+    np.savez_compressed(os.path.join(OUT, "pareto.npz"), **out)
+    print("pareto", [int(out[f"efficient_{k}"].sum()) for k in range(len(shapes))])
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference not present; nothing to do")
@@ -437,6 +465,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--only-generative-mi":
         case_mi_generative(mi, "k64_v500", 26, 64, 500, False)
         case_mi_generative(mi, "k128_v600_peaked", 27, 128, 600, True)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-pareto":
+        case_pareto(32)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "--only-round2":
         case_kde_batch(kde, 30)
@@ -474,6 +505,7 @@ def main():
     case_grad(lo, "d128", 29, 32, 32, 128)
     case_kde_batch(kde, 30)
     case_gll_generic(mi, 31)
+    case_pareto(32)
 
 
 if __name__ == "__main__":

@@ -57,3 +57,20 @@ def test_pareto_filter_host_logic():
         pareto_check_use_tts_mmd = True
         pareto_check_use_elbo = False
     assert list(prepare_pareto_dict(Cfg()).keys()) == ["kl_analytical", "-tts_mmd"]
+
+
+def test_pareto_filter_pinned_to_the_reference():
+    """tests/golden/pareto.npz: gain matrices (ties, duplicates, a dominated point ahead of its dominator, one column,
+    one point) and the masks the REFERENCE's is_pareto_efficient_simple returned for them (utils_train.py:416-431,
+    run from its own FunctionDef by tests/golden/make_golden.py) -- both the product's vectorised filter and the
+    oracle's brute-force restatement must reproduce every mask."""
+    from conftest import load_golden
+    from lvae.pareto import is_pareto_efficient_simple
+    g = load_golden("pareto")
+    n_cases = int(g["n_cases"])
+    assert n_cases >= 8
+    for k in range(n_cases):
+        gains, want = g[f"gains_{k}"], g[f"efficient_{k}"]
+        assert want.dtype == bool and want.shape == (gains.shape[0],)
+        np.testing.assert_array_equal(is_pareto_efficient_simple(gains), want, err_msg=f"case {k}")
+        np.testing.assert_array_equal(onp.is_pareto_efficient(gains), want, err_msg=f"oracle, case {k}")
