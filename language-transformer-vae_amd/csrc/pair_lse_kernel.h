@@ -72,7 +72,25 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 //        Y[c][p] += sum_r K[r][c] L[r][p].  Every PERM_FLUSH blocks the lane folds
 //        sum_c L[c][p] Y[c][p] into a float64 and clears Y; at the end q_p = L_p^T K L_p partials go
 //        to `qperm` with float64 atomics.
-#define PERM_FLUSH 16
+#ifndef PERM_FLUSH
+#define PERM_FLUSH 64
+#endif
+// Development switches of this template (A/B builds; the defaults are the product):
+//   LVAE_EPI_ANCHOR  1: every epilogue micro-slice ends in an empty volatile asm that names its results, so that no IR
+//                    pass can sink the slice's arithmetic past the MFMA slots it was placed between (without it the
+//                    split-bf16 permutation kernel came out as 12 MFMAs, then the whole epilogue in one lump)
+//   LVAE_COND_MASK   1: the diagonal-exclusion mask is only built for blocks that hold the diagonal (wave-uniform branch
+//                    between two copies of the block body)
+//   LVAE_KS_F32      1: PERM: tile sums are folded in float32 between flushes, float64 only at a flush
+#ifndef LVAE_EPI_ANCHOR
+#define LVAE_EPI_ANCHOR 1
+#endif
+#ifndef LVAE_COND_MASK
+#define LVAE_COND_MASK 1
+#endif
+#ifndef LVAE_KS_F32
+#define LVAE_KS_F32 1
+#endif
 
 typedef __bf16 lvae_bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -136,6 +154,7 @@ pair_lse_body(const float* __restrict__ rfrag, const float* __restrict__ rbias,
     float m[NCB], s[NCB];
     double ks[NCB];       // EPI 1: float64 column sums
     double ksd = 0.0;     // PERM + sym: column sums of the diagonal tile
+    float ksf = 0.f;      // PERM (LVAE_KS_F32): tile sums since the last flush (<= PERM_FLUSH tiles of <= 16 * n_alpha each)
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         m[cb] = LSE_MINIT;
@@ -349,11 +368,18 @@ pair_lse_body(const float* __restrict__ rfrag, const float* __restrict__ rbias,
                     kv[2 * ms] = kval.x;
                     kv[2 * ms + 1] = kval.y;
                 }
+#if LVAE_EPI_ANCHOR
+                if (PERM) asm volatile("" : "+v"(kt2[cb]), "+v"(kv[2 * ms]), "+v"(kv[2 * ms + 1]));
+                else asm volatile("" : "+v"(kt2[cb]));
+#endif
             } else if (PERM) {
                 // strictly-upper (or, without sym, all) tiles and the diagonal tile are kept apart
                 const float ts = kt2[cb].x + kt2[cb].y;
                 if (use_sym && wgt[cb] == 1.f) ksd += (double)ts;
-                else if (!use_sym || wgt[cb] == 2.f) ks[cb] += (double)ts;
+                else if (!use_sym || wgt[cb] == 2.f) {
+                    if (LVAE_KS_F32) ksf += ts;
+                    else ks[cb] += (double)ts;
+                }
             } else {
                 ks[cb] += (double)((kt2[cb].x + kt2[cb].y) * wgt[cb]);
             }
@@ -420,17 +446,31 @@ pair_lse_body(const float* __restrict__ rfrag, const float* __restrict__ rbias,
         }
     }
     auto perm_flush = [&](float wv) __attribute__((always_inline)) {
+        // (the masks are re-read through an opaque asm: left to itself the compiler hoists all 80 per-bit lane masks
+        //  out of the loop as scalar register pairs, spills them into vector lanes and pays 130 v_readlane per flush)
+        const bool full = __builtin_amdgcn_readfirstlane((int)__all(vmask == 0xFFFFu)) != 0;
 #pragma unroll
         for (int pt = 0; pt < (PERM ? 4 : 0); ++pt) {
+            unsigned cm = cmask[pt], vm = vmask;
+            asm volatile("" : "+v"(cm), "+v"(vm));
             float t = 0.f, u = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                t += ((cmask[pt] >> e) & 1u) ? Y[pt][e] : 0.f;
-                u += ((vmask >> e) & 1u) ? Y[pt][e] : 0.f;
-                Y[pt][e] = 0.f;
+            for (int e = 0; e < 16; ++e) t = __builtin_fmaf((float)((cm >> e) & 1u), Y[pt][e], t);
+            if (full) {       // (one wave-uniform branch per labeling tile, not one per element)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) u += Y[pt][e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) u = __builtin_fmaf((float)((vm >> e) & 1u), Y[pt][e], u);
             }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Y[pt][e] = 0.f;
             qacc[pt] += (double)(t * wv);
             yacc[pt] += (double)u;
+        }
+        if (LVAE_KS_F32) {
+            ks[0] += (double)ksf;
+            ksf = 0.f;
         }
     };
     // kv (the finished tile, accumulator layout: lane = column, 16 rows) -> two bf16 limbs -> 16 MFMAs
@@ -440,6 +480,8 @@ pair_lse_body(const float* __restrict__ rfrag, const float* __restrict__ rbias,
         // (a scalar branch, not a test of the per-lane copy of the weight: MFMA ignores EXEC, and the compiler may lower a
         //  short conditional block to EXEC masking without a jump)
         if (__builtin_amdgcn_readfirstlane(__float_as_int(wv)) == 0) return;
+        const bf16x8* lb = reinterpret_cast<const bf16x8*>(lring + lstage * LAB_F);
+        bf16x8 bcur = lb[lane];            // (the limb split below covers this read's latency)
         bf16x8 ahi[2], alo[2];
 #pragma unroll
         for (int sp = 0; sp < 2; ++sp)
@@ -454,12 +496,12 @@ pair_lse_body(const float* __restrict__ rfrag, const float* __restrict__ rbias,
                 alo[sp][2 * e2] = ll[0];
                 alo[sp][2 * e2 + 1] = ll[1];
             }
-        const bf16x8* lb = reinterpret_cast<const bf16x8*>(lring + lstage * LAB_F);
 #pragma unroll
         for (int pt = 0; pt < (PERM ? 4 : 0); ++pt)
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
-                const bf16x8 b = lb[(pt * 2 + sp) * 64 + lane];
+                const bf16x8 b = bcur;
+                if (pt * 2 + sp + 1 < 8) bcur = lb[(pt * 2 + sp + 1) * 64 + lane];
                 Y[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[sp], b, Y[pt], 0, 0, 0);
                 Y[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[sp], b, Y[pt], 0, 0, 0);
             }
@@ -471,6 +513,11 @@ pair_lse_body(const float* __restrict__ rfrag, const float* __restrict__ rbias,
 
     constexpr int SLOTS = BX ? NS * 6 * NCB : DP * NCB;   // MFMAs per block
     constexpr int MS_TOTAL = EPI_MS * NCB;             // micro-slices per block
+    // Kernel-sum epilogues issue their slices in PAIRS behind one MFMA: a slice is one dependent chain of packed fp32
+    // operations (the polynomial), and the hardware wants a wait state between dependent packed operations -- two
+    // independent chains in one scheduling region fill each other's wait states (47 s_nop per tile otherwise).
+    constexpr int MSG = KS ? 2 : 1;                    // slices per group
+    constexpr int NG = (MS_TOTAL + MSG - 1) / MSG;     // groups per block
 
     // Values carried from the tail of one chunk into the next: the first 1 KiB piece of the next chunk
     // and (at a block boundary) the next block's row biases, both already read from LDS.
@@ -504,8 +551,22 @@ pair_lse_body(const float* __restrict__ rfrag, const float* __restrict__ rbias,
     int t_lin = 0;                                         // chunks consumed so far by this wave
     auto run_block = [&](f32x16 (&acc)[NCB], const f32x16 (&prev)[NCB], int64_t blk, bool with_epi) __attribute__((always_inline)) {
         const f32x16 cv = c_pre;
-        f32x16 cvm[EXCL ? NCB : 1];
-        if constexpr (EXCL) {
+        // EXCL: only a block whose rows meet one of the wave's column blocks on the excluded diagonal needs masked
+        // biases (16 moves + 16 compare / select per column block).  LVAE_COND_MASK: the first MFMA of the chain is
+        // issued from one of two places under a wave-uniform branch -- with the masked copy, built on the spot, or
+        // straight from the biases as they were read.
+        constexpr bool MASKED = EXCL && !LVAE_COND_MASK;      // every block builds the masked copy up front
+        bool hit = false;
+        if constexpr (EXCL && LVAE_COND_MASK) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const int64_t cbase = col0 + cb * 32 + excl_offset;
+                hit = hit || (blk * 32 < cbase + 32 && blk * 32 + 32 > cbase);
+            }
+            hit = __builtin_amdgcn_readfirstlane((int)hit) != 0;
+        }
+        f32x16 cvm[MASKED ? NCB : 1];
+        if constexpr (MASKED) {
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 cvm[cb] = cv;
@@ -534,14 +595,22 @@ pair_lse_body(const float* __restrict__ rfrag, const float* __restrict__ rbias,
                 for (int pr = 0; pr < 6; ++pr) {
 #pragma unroll
                     for (int cb = 0; cb < NCB; ++cb) {
+                        if (EXCL && LVAE_COND_MASK && sx == 0 && pr == 0 && hit) {
+                            f32x16 cm = cv;
+                            mask_bias(cm, cb, blk);
+                            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[0][LA[0]], bzx[cb][0][LB[0]], cm, 0, 0, 0);
+                        } else {
                         acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[sx & 1][LA[pr]], bzx[cb][sx][LB[pr]],
-                                                                          (sx == 0 && pr == 0) ? (EXCL ? cvm[EXCL ? cb : 0] : cv) : acc[cb],
+                                                                          (sx == 0 && pr == 0) ? (MASKED ? cvm[MASKED ? cb : 0] : cv) : acc[cb],
                                                                           0, 0, 0);
+                        }
                         const int u = (sx * 6 + pr) * NCB + cb;
                         if (with_epi) {
 #pragma unroll
-                            for (int k = (u * MS_TOTAL) / SLOTS; k < ((u + 1) * MS_TOTAL) / SLOTS; ++k)
-                                epi_micro(prev, k / EPI_MS, k % EPI_MS);
+                            for (int gk = (u * NG) / SLOTS; gk < ((u + 1) * NG) / SLOTS; ++gk)
+#pragma unroll
+                                for (int k = gk * MSG; k < (gk + 1) * MSG && k < MS_TOTAL; ++k)
+                                    epi_micro(prev, k / EPI_MS, k % EPI_MS);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -581,13 +650,20 @@ pair_lse_body(const float* __restrict__ rfrag, const float* __restrict__ rbias,
                     const int st = ch * CS + q * 4 + e;
 #pragma unroll
                     for (int cb = 0; cb < NCB; ++cb) {
+                        if (EXCL && LVAE_COND_MASK && st == 0 && hit) {
+                            f32x16 cm = cv;
+                            mask_bias(cm, cb, blk);
+                            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0][0], bz[cb][0], cm, 0, 0, 0);
+                        } else
                         acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q & 1][e], bz[cb][st],
-                                                                       st == 0 ? (EXCL ? cvm[EXCL ? cb : 0] : cv) : acc[cb], 0, 0, 0);
+                                                                       st == 0 ? (MASKED ? cvm[MASKED ? cb : 0] : cv) : acc[cb], 0, 0, 0);
                         const int u = st * NCB + cb;
-                        if (with_epi) {   // micro-slices spread evenly over the block's MFMA slots
+                        if (with_epi) {   // micro-slices (kernel sums: pairs of them) spread evenly over the block's MFMA slots
 #pragma unroll
-                            for (int k = (u * MS_TOTAL) / SLOTS; k < ((u + 1) * MS_TOTAL) / SLOTS; ++k)
-                                epi_micro(prev, k / EPI_MS, k % EPI_MS);
+                            for (int gk = (u * NG) / SLOTS; gk < ((u + 1) * NG) / SLOTS; ++gk)
+#pragma unroll
+                                for (int k = gk * MSG; k < (gk + 1) * MSG && k < MS_TOTAL; ++k)
+                                    epi_micro(prev, k / EPI_MS, k % EPI_MS);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -645,6 +721,7 @@ pair_lse_body(const float* __restrict__ rfrag, const float* __restrict__ rbias,
         if (PERM) {
             perm_tile((int)((b1 - 1 - b0) % NSTL), wgt[0]);
             if (pcount) perm_flush(wgt[0]);
+            if (LVAE_KS_F32) ks[0] += (double)ksf;      // (tiles of weight 0 fold nothing into Y but do count here)
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) {
                 const double tot = qacc[pt] + __shfl_xor(qacc[pt], 32, 64);
