@@ -36,9 +36,13 @@ def main():
     want_sums, want_lq = want_sums.cpu(), want_lq.cpu()
 
     # 1. the overlapped exchange: async all-gather on RCCL's stream, own block meanwhile, stream-side wait
-    packed = torch.cat([mu, logvar], dim=1).contiguous()
-    for _ in range(3):
-        sums, lq, n_total = LD.overlapped_stats(packed, z, mu, logvar, None, lambda nt: math.log(nt))
+    #    (mu and logvar are gathered as two collectives and read in place)
+    tl = LD.Timeline(dev)
+    for it in range(3):
+        sums, lq, n_total = LD.overlapped_stats(mu, logvar, z, None, lambda nt: math.log(nt),
+                                                timeline=tl if it == 2 else None)
+    phases = tl.phases_ms()
+    assert "own_block" in phases and "wait_all_gather" in phases, phases
     assert n_total == n
     assert torch.allclose(lq.cpu(), want_lq, rtol=0, atol=2e-5), float((lq.cpu() - want_lq).abs().max())
     assert torch.allclose(sums.cpu(), want_sums, rtol=1e-6), (sums.cpu(), want_sums)   # (two-block logsumexp)
