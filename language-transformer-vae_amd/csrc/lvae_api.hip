@@ -211,7 +211,7 @@ static void load_switches() {
     s.iw_u = (int)num("LVAE_IW_U", 0);
     s.iw_tpb = (int)num("LVAE_IW_TPB", 0);
     s.iw_no_stage = getenv("LVAE_IW_NO_STAGE") != nullptr;
-    s.iw_batch = (int)num("LVAE_IW_BATCH", 0);
+    s.iw_plain_stores = getenv("LVAE_IW_PLAIN_STORES") != nullptr;
     s.mmd_bx_min_pairs = num("LVAE_MMD_BX_MIN_PAIRS", -1);
     g_switches = s;
 }

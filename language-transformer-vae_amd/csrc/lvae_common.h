@@ -55,7 +55,7 @@ struct LvaeSwitches {
     int iw_pipe;                  // LVAE_IW_PIPE: -1 unset, 0 / 1
     int iw_u, iw_tpb;             // LVAE_IW_U / LVAE_IW_TPB (0: unset)
     bool iw_no_stage;             // LVAE_IW_NO_STAGE
-    int iw_batch;                 // LVAE_IW_BATCH: sentences per workgroup of the density-writing IW form (0: built-in)
+    bool iw_plain_stores;         // LVAE_IW_PLAIN_STORES: the staged [B,K] rows leave as plain stores (default: write-through, sc1)
     long long mmd_bx_min_pairs;   // LVAE_MMD_BX_MIN_PAIRS: smallest n1*n2 at which AUTO takes the split-bf16 kernel sums (< 0: built-in)
 };
 const LvaeSwitches& lvae_switches();

@@ -32,8 +32,16 @@
 
 // floats of one 32-row record: density operand | features | tail = group biases [DP/8][32], normaliser [32], g [32]
 // (the tail padded to whole 64-float DMA pieces)
+// BX (D <= 32): the features are stored as three bf16 limbs each, in the fragment order of v_mfma_f32_32x32x16_bf16
+// (see the sweep kernel): (DP / 16) feature tiles x 2 k-groups x 3 limbs pieces of 1 KiB.
 #define BWD_TAIL_PIECES(DP) (((DP) / 8 + 2 + 1) / 2)
-#define BWD_REC_F(DP) (128 * (DP) + 64 * BWD_TAIL_PIECES(DP))
+#define BWD_BX(DP) ((DP) <= 32)
+#define BWD_FEAT_F(DP) (BWD_BX(DP) ? ((DP) / 16) * 6 * 256 : 64 * (DP))
+#define BWD_TAIL_OFF(DP) (64 * (DP) + BWD_FEAT_F(DP))
+#define BWD_REC_F(DP) (BWD_TAIL_OFF(DP) + 64 * BWD_TAIL_PIECES(DP))
+
+typedef __bf16 bwd_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bwd_bf16x2 __attribute__((ext_vector_type(2)));
 
 // ---- operand preparation ---------------------------------------------------------------------------------------
 // One workgroup per 32-row block; blocks below nblk_j hold posteriors, the others samples.  Every block is written
@@ -129,19 +137,41 @@ bwd_prep_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, 
         const int e = idx & 3, row = (idx >> 2) & 31, h = (idx >> 7) & 1, sg = idx >> 8;     // slot = lane = row + 32 h
         rec[idx] = dens(row, h, 4 * sg + e);
     }
-    for (int idx = tid; idx < 64 * DP; idx += 256) {       // A operand of the feature contraction: [f/32][q][h][f%32][e]
-        const int e = idx & 3, fl = (idx >> 2) & 31, h = (idx >> 7) & 1, q = (idx >> 8) & 3, ft = idx >> 10;
-        const int f = ft * 32 + fl, row = 8 * q + 4 * h + e;
+    auto feat = [&](int row, int f) -> float {
         const int half = f >= DP, d = f - half * DP;
         const float v = p0[row * LD + d];
-        float o;
-        if (post) o = half ? v * p1[row * LD + d] : p1[row * LD + d];
-        else o = half ? v : v * v;
-        rec[64 * DP + idx] = o;
+        if (post) return half ? v * p1[row * LD + d] : p1[row * LD + d];
+        return half ? v : v * v;
+    };
+    if (BWD_BX(DP)) {
+        // A operand of the feature contraction on the bf16 pipe: piece ((t * 2 + s) * 3 + limb) holds, for lane
+        // (f % 32) + 32 h, the eight k-entries i of k-group s -- streamed row 16 s + 8 (i / 4) + 4 h + (i % 4), the row
+        // that register 8 s + i of a 32x32 fp32 accumulator holds on half-wave h
+        unsigned short* fr = reinterpret_cast<unsigned short*>(rec + 64 * DP);
+        for (int idx = tid; idx < (DP / 16) * 2 * 512; idx += 256) {
+            const int i = idx & 7, lane = (idx >> 3) & 63, s2 = (idx >> 9) & 1, t = idx >> 10;
+            const int fl = lane & 31, h = lane >> 5;
+            const int row = 16 * s2 + 8 * (i >> 2) + 4 * h + (i & 3);
+            const float o = feat(row, 32 * t + fl);
+            const __bf16 hb = (__bf16)o;
+            const float r1 = o - (float)hb;
+            const __bf16 mb = (__bf16)r1;
+            const __bf16 lb = (__bf16)(r1 - (float)mb);
+            const int pbase = ((t * 2 + s2) * 3) * 512 + lane * 8 + i;
+            fr[pbase] = __builtin_bit_cast(unsigned short, hb);
+            fr[pbase + 512] = __builtin_bit_cast(unsigned short, mb);
+            fr[pbase + 1024] = __builtin_bit_cast(unsigned short, lb);
+        }
+    } else {
+        for (int idx = tid; idx < 64 * DP; idx += 256) {       // A operand of the feature contraction: [f/32][q][h][f%32][e]
+            const int e = idx & 3, fl = (idx >> 2) & 31, h = (idx >> 7) & 1, q = (idx >> 8) & 3, ft = idx >> 10;
+            rec[64 * DP + idx] = feat(8 * q + 4 * h + e, ft * 32 + fl);
+        }
     }
-    for (int idx = tid; idx < 32 * G; idx += 256) rec[128 * DP + idx] = sm_gb[idx];
-    if (tid < 32) rec[128 * DP + 32 * G + tid] = sm_bias[tid];
-    else if (tid < 64) rec[128 * DP + 32 * G + tid] = sm_g[tid - 32];
+    const int toff = BWD_TAIL_OFF(DP);
+    for (int idx = tid; idx < 32 * G; idx += 256) rec[toff + idx] = sm_gb[idx];
+    if (tid < 32) rec[toff + 32 * G + tid] = sm_bias[tid];
+    else if (tid < 64) rec[toff + 32 * G + tid] = sm_g[tid - 32];
     for (int idx = tid; idx < 64 * DP; idx += 256) {       // kept-axis rows [row][h][s]
         const int s = idx % DP, h = (idx / DP) & 1, row = idx / (2 * DP);
         cop[idx] = dens(row, h, s);
@@ -160,9 +190,10 @@ pair_bwd_mfma_kernel(const float* __restrict__ rec, const float* __restrict__ co
                      const float* __restrict__ colgb, int64_t nblk, int64_t blk_per_split, int64_t cpad, float* __restrict__ partial,
                      float* __restrict__ wsum_out, const PairHeader* __restrict__ hdr, float cond_limit) {
     if (cond_limit >= 0.f && __uint_as_float(hdr->cond_bits) > cond_limit) return;
+    constexpr bool BX = BWD_BX(DP);
     constexpr int REC = BWD_REC_F(DP);
     constexpr int NFT = DP / 16;                  // 32-wide tiles of the 2 DP feature columns
-    constexpr int PIECES = DP / 2;                // 1 KiB DMA pieces of a record (without the bias piece)
+    constexpr int PIECES = BWD_TAIL_OFF(DP) / 256;    // 1 KiB DMA pieces of a record (without the tail)
     __shared__ __attribute__((aligned(16))) float ring[2 * REC];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -205,7 +236,8 @@ pair_bwd_mfma_kernel(const float* __restrict__ rec, const float* __restrict__ co
 #pragma unroll
         for (int q0 = 0; q0 < PIECES; q0 += 4) {
             const int q = q0 + wave;
-            __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + q * 1024 + lane16), (lptr_t)(l + q * 256), 16, 0, 0);
+            if (PIECES % 4 == 0 || q < PIECES)
+                __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + q * 1024 + lane16), (lptr_t)(l + q * 256), 16, 0, 0);
         }
 #pragma unroll
         for (int t0 = 0; t0 < BWD_TAIL_PIECES(DP); t0 += 4) {      // 64 lanes x 4 B: two 32-row vectors of the tail
@@ -224,7 +256,7 @@ pair_bwd_mfma_kernel(const float* __restrict__ rec, const float* __restrict__ co
         if (blk + 1 < b1) dma_block(blk + 1, stage ^ 1);
         const float* st = ring + stage * REC;
         constexpr int G = DP / 8;
-        const float* tail = st + 128 * DP;
+        const float* tail = st + BWD_TAIL_OFF(DP);
         f32x16 tot;
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
@@ -267,6 +299,46 @@ pair_bwd_mfma_kernel(const float* __restrict__ rec, const float* __restrict__ co
         }
 #pragma unroll
         for (int v = 0; v < 16; ++v) wsum += w[v];
+        if constexpr (BX) {
+            // The feature contraction on the bf16 matrix pipe at fp32-equivalent accuracy: the tile of weights --
+            // lane = column, registers = rows -- is split into three bf16 limbs (w = h + m + l, 8 + 8 + 8 mantissa bits)
+            // and is, register for register, the B operand of v_mfma_f32_32x32x16_bf16 over the 16 rows of k-group s
+            // (registers 8 s .. 8 s + 7); the features come from the record as limb fragments in the same row order.
+            // Six limb products of weight >= 2^-16 per k-group (the dropped three are below 2^-24 of the product):
+            // 12 MFMAs of 32 cycles per 32 feature columns instead of 16 of 64, off the fp32 lanes.
+            bwd_bf16x8 wl[2][3];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    const f32x2 v = {w[8 * s2 + 2 * pr], w[8 * s2 + 2 * pr + 1]};
+                    const bwd_bf16x2 hh = __builtin_convertvector(v, bwd_bf16x2);
+                    const f32x2 r1 = v - __builtin_convertvector(hh, f32x2);
+                    const bwd_bf16x2 mm = __builtin_convertvector(r1, bwd_bf16x2);
+                    const f32x2 r2 = r1 - __builtin_convertvector(mm, f32x2);
+                    const bwd_bf16x2 ll = __builtin_convertvector(r2, bwd_bf16x2);
+                    wl[s2][0][2 * pr] = hh[0];
+                    wl[s2][0][2 * pr + 1] = hh[1];
+                    wl[s2][1][2 * pr] = mm[0];
+                    wl[s2][1][2 * pr + 1] = mm[1];
+                    wl[s2][2][2 * pr] = ll[0];
+                    wl[s2][2][2 * pr + 1] = ll[1];
+                }
+            constexpr int LA[6] = {1, 2, 0, 1, 0, 0};     // limb of the features (A), smallest products first
+            constexpr int LB[6] = {1, 0, 2, 0, 1, 0};     // limb of the weights (B)
+            const uint4* fr = reinterpret_cast<const uint4*>(st + 64 * DP) + lane;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int t = 0; t < NFT; ++t) {
+                    bwd_bf16x8 fa[3];
+#pragma unroll
+                    for (int l = 0; l < 3; ++l) fa[l] = __builtin_bit_cast(bwd_bf16x8, fr[((t * 2 + s2) * 3 + l) * 64]);
+#pragma unroll
+                    for (int pr = 0; pr < 6; ++pr)
+                        oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[LA[pr]], wl[s2][LB[pr]], oacc[t], 0, 0, 0);
+                }
+        } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 f4[NFT];
@@ -278,6 +350,7 @@ pair_bwd_mfma_kernel(const float* __restrict__ rec, const float* __restrict__ co
 #pragma unroll
                 for (int t = 0; t < NFT; ++t)
                     oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4[t][e], w[4 * q + e], oacc[t], 0, 0, 0);
+        }
         }
     }
     // out[f][c]: lane (c, h) holds f = 32 t + 8 q + 4 h + e in register 4 q + e of tile t
@@ -309,7 +382,7 @@ bwd_rescale_g_kernel(const float* __restrict__ wsum, int nsplit, int64_t cpad, c
     for (int k = 0; k < nsplit; ++k) sum += wsum[(int64_t)k * cpad + i];
     const float gs = sum > 0.f ? g[i] / sum : 0.f;
     gscaled[i] = gs;
-    rec_i[(i >> 5) * (int64_t)BWD_REC_F(DP) + 128 * DP + 32 * (DP / 8 + 1) + (i & 31)] = gs;
+    rec_i[(i >> 5) * (int64_t)BWD_REC_F(DP) + BWD_TAIL_OFF(DP) + 32 * (DP / 8 + 1) + (i & 31)] = gs;
 }
 
 // ---- merges ------------------------------------------------------------------------------------------------------
@@ -373,7 +446,8 @@ BwdMfmaLayout lvae_bwd_mfma_layout(int64_t M, int64_t N, int D) {
     if (L.DP == 0) return L;
     L.cpad_i = lvae_round_up(M, 128);
     L.cpad_j = lvae_round_up(N, 128);
-    const int64_t slots = 256 * (L.DP <= 64 ? 2 : 1);
+    // workgroups resident per CU: by LDS (two ring stages of a record) and registers
+    const int64_t slots = 256 * (L.DP <= 16 ? 4 : (L.DP <= 32 ? 3 : (L.DP <= 64 ? 2 : 1)));
     auto split = [&](int64_t kept_pad, int64_t rows, int* ns, int64_t* bps) {
         const int64_t groups = kept_pad / 128, nblk = lvae_ceil_div(rows, 32);
         int64_t c = (2 * slots + groups / 2) / groups;

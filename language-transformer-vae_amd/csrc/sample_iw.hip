@@ -105,15 +105,27 @@ __device__ __forceinline__ f32x2 mul_then_add(f32x2 m, f32x2 e, f32x2 sd) {
     return m + t;
 }
 
-template <bool FROM_EPS, int U, int TPB, bool PIPE>
+// IO (compile time, so that every trip of the stream issues the same memory operations and the compiler's counted
+// waits are exact -- with run-time conditions around a load or store it falls back to vmcnt(0), a full drain of the
+// loads that were just issued, in every trip): bit 0 = log_p_x_z is read (iw_ll wanted and the tensor given),
+// bit 1 = z is written.
+template <bool FROM_EPS, int U, int TPB, bool PIPE, int IO>
 __global__ void __launch_bounds__(TPB)
 sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
                  const float* __restrict__ src, const float* __restrict__ log_p_x_z, int64_t K, int D,
                  int G, float* __restrict__ z_out, float* __restrict__ log_q_z_x,
                  float* __restrict__ log_p_z, float* __restrict__ iw_ll, int stage) {
+    constexpr bool HAS_PXZ = (IO & 1) != 0;
+    constexpr bool WRITE_Z = FROM_EPS && (IO & 2) != 0;
     // stage != 0 (K a multiple of 4, 2*K floats of dynamic LDS): the sentence's two [K] output rows are collected in
     // LDS and leave as full 16-byte-per-lane stores at the end, instead of one 128-byte piece per wave and pass
-    // (131 MB of such pieces cost the C5 stream 0.06 ms: 0.39 -> 0.33 ms without them)
+    // (131 MB of such pieces cost the C5 stream 0.06 ms: 0.39 -> 0.33 ms without them); stage & 2: those stores are
+    // write-through (sc1), the default: 0.372 against 0.380 ms at C5.  What the outputs still cost is a property of
+    // the memory system, not of this kernel (tools/ubench/rw_mix.cpp: a bare read of the same 2.1 GB takes 0.294 ms,
+    // 0.377 ms with 8,000 bytes stored after every 128,000 read -- whichever wave stores them, plain, nt or sc1 --
+    // and 0.32-0.33 ms only when ALL stores fall together at the end of the kernel, which needs the outputs of a
+    // whole launch in LDS: a wave-per-sentence form with one burst per workgroup, and the same as one round of
+    // workgroups per launch, were built and measured at 0.377 / 0.370 ms and dropped)
     extern __shared__ __attribute__((aligned(16))) float iw_stage[];
     const int64_t b = blockIdx.x;
     const int gl = threadIdx.x % G;          // lane inside the row group: owns dims 4*gl .. 4*gl+3
@@ -128,27 +140,39 @@ sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
     const int wave_rows = Gw * U;
     const int64_t kw0 = (int64_t)(threadIdx.x >> 6) * wave_rows + gw;           // row of load 0 in pass 0
     // (unconditional loads: a row past the end is clamped to the last one -- its results are never owned by a lane
-    //  -- so that a pass is straight-line code and the waits on its loads are counted ones)
+    //  -- so that a pass is straight-line code and the waits on its loads are counted ones; log_p_x_z rides along:
+    //  every lane of a row group loads the element of the row that lane gl % U will own)
     const int64_t klast = K - 1;
-    auto issue = [&](f32x4 (&v)[U], int64_t kw) {
+    auto issue = [&](f32x4 (&v)[U], float& p, int64_t kw) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t row = kw + u * Gw < klast ? kw + u * Gw : klast;
             v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + row * D + 4 * gl));
         }
+        if (HAS_PXZ) {
+            const int64_t kr = kw + (int64_t)(gl % U) * Gw;
+            p = log_p_x_z[b * K + (kr < klast ? kr : klast)];
+        }
     };
-    // The stream is software-pipelined over two register buffers: the loads of pass p + 1 are in flight while pass
-    // p is reduced (7 dependent shuffles per quantity), and the first pass is issued before the per-lane constants
-    // -- which hang on a load of their own -- are formed.
-    f32x4 va[U], vb[U];
-    issue(va, kw0);
     // per-lane constants of the four dimensions, as two packed pairs: mean, sigma, sqrt(0.5 / var); the constant
-    // part of the row's log q(z|x), -0.5 (logvar + log 2pi), is summed once
+    // part of the row's log q(z|x), -0.5 (logvar + log 2pi), is summed once.  Their two loads go out FIRST: memory
+    // operations complete in order, so they are back before the first pass, whose loads stay in flight while the
+    // constants are formed.
+    // (unconditional, from an address that is valid either way: a branch around them would put the wait for them at
+    //  its end, ahead of the first pass)
+    f32x4 m4 = *reinterpret_cast<const f32x4*>((have_post ? mu + b * D : base) + 4 * gl);
+    f32x4 lv4 = *reinterpret_cast<const f32x4*>((have_post ? logvar + b * D : base) + 4 * gl);
+    // The stream is software-pipelined over two register buffers: the loads of pass p + 1 are in flight while pass
+    // p is reduced (7 dependent shuffles per quantity).
+    f32x4 va[U], vb[U];
+    float pa = 0.f, pb = 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+    issue(va, pa, kw0);
+    __builtin_amdgcn_sched_barrier(0);      // (or the constants' arithmetic, and the wait for their loads, moves ahead of the first pass)
+    asm volatile("" : "+v"(m4), "+v"(lv4)); // (both loads stay where they are: left alone, the compiler sinks one into the branch below)
     f32x2 m2[2] = {{0.f, 0.f}, {0.f, 0.f}}, sd2[2] = {{0.f, 0.f}, {0.f, 0.f}}, sh2[2] = {{0.f, 0.f}, {0.f, 0.f}};
     float cq = 0.f;
     if (have_post) {
-        const f32x4 m4 = *reinterpret_cast<const f32x4*>(mu + b * D + 4 * gl);
-        const f32x4 lv4 = *reinterpret_cast<const f32x4*>(logvar + b * D + 4 * gl);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             m2[e >> 1][e & 1] = m4[e];
@@ -157,13 +181,14 @@ sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
             cq += -0.5f * (lv4[e] + LVAE_LOG_2PI);
         }
     }
+    // (the means are only renamed above: without this anchor their first use, and with it the wait for their load,
+    //  sinks into the loop, where it can only be a vmcnt(0))
+    asm volatile("" : "+v"(m2[0]), "+v"(m2[1]));
     const float cp = -0.5f * LVAE_LOG_2PI * 4.0f;
     float lm = -INFINITY, ls = 0.f;
-    auto consume = [&](const f32x4 (&v)[U], int64_t kw) {
+    auto consume = [&](const f32x4 (&v)[U], float pxz, int64_t kw) {
         const int64_t kmine = kw + (int64_t)(gl % U) * Gw;     // the row whose results this lane will own
         const bool mine = gl < U && kmine < K;
-        float pxz = 0.f;
-        if (mine && iw_ll && log_p_x_z) pxz = log_p_x_z[b * K + kmine];
         // packed fp32 throughout (two dimensions per instruction): -(z - mu)^2 / (2 var) as the square of
         // (z - mu) * sqrt(0.5 / var), -z^2 / 2 from the plain sum of squares
         float aq[U], ap[U];
@@ -183,8 +208,10 @@ sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
                 zz4[2 * h] = zz[0];
                 zz4[2 * h + 1] = zz[1];
             }
-            if (FROM_EPS && z_out && kw + u * Gw < K)
-                __builtin_nontemporal_store(zz4, reinterpret_cast<f32x4*>(z_out + (b * K + kw + u * Gw) * D + 4 * gl));
+            if (WRITE_Z) {      // (a row past the end repeats the last row's store: same address, same value)
+                const int64_t row = kw + u * Gw < klast ? kw + u * Gw : klast;
+                __builtin_nontemporal_store(zz4, reinterpret_cast<f32x4*>(z_out + (b * K + row) * D + 4 * gl));
+            }
             aq[u] = cq - (q2[0] + q2[1]);
             ap[u] = cp - 0.5f * (p2[0] + p2[1]);
             __builtin_amdgcn_sched_barrier(0);      // one row at a time: interleaved rows only lengthen live ranges
@@ -203,21 +230,29 @@ sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
         }
     };
     if (PIPE) {
-        for (int64_t k0 = 0; k0 < K; k0 += 2 * rows_per_iter) {
-            const bool second = k0 + rows_per_iter < K;
-            if (second) issue(vb, kw0 + k0 + rows_per_iter);
+        // every trip of the main loop: two passes consumed, two issued, nothing conditional
+        int64_t k0 = 0;
+        for (; k0 + 2 * rows_per_iter < K; k0 += 2 * rows_per_iter) {
+            issue(vb, pb, kw0 + k0 + rows_per_iter);
             __builtin_amdgcn_sched_barrier(0);      // (keeps the two passes' arithmetic apart: interleaved, their
-            consume(va, kw0 + k0);                  //  live ranges cost 40 registers and two waves per SIMD)
+            consume(va, pa, kw0 + k0);              //  live ranges cost 40 registers and two waves per SIMD)
             __builtin_amdgcn_sched_barrier(0);
-            if (k0 + 2 * rows_per_iter < K) issue(va, kw0 + k0 + 2 * rows_per_iter);
+            issue(va, pa, kw0 + k0 + 2 * rows_per_iter);
             __builtin_amdgcn_sched_barrier(0);
-            if (second) consume(vb, kw0 + k0 + rows_per_iter);
+            consume(vb, pb, kw0 + k0 + rows_per_iter);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // the last one or two passes
+        const bool second = k0 + rows_per_iter < K;
+        if (second) issue(vb, pb, kw0 + k0 + rows_per_iter);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(va, pa, kw0 + k0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (second) consume(vb, pb, kw0 + k0 + rows_per_iter);
     } else {
         for (int64_t k0 = 0; k0 < K; k0 += rows_per_iter) {
-            if (k0) issue(va, kw0 + k0);
-            consume(va, kw0 + k0);
+            if (k0) issue(va, pa, kw0 + k0);
+            consume(va, pa, kw0 + k0);
         }
     }
     if (stage) {
@@ -225,8 +260,19 @@ sample_iw_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
         const f32x4* sq = reinterpret_cast<const f32x4*>(iw_stage);
         const f32x4* sp = reinterpret_cast<const f32x4*>(iw_stage + K);
         for (int i = threadIdx.x; i < (int)(K >> 2); i += TPB) {
-            if (log_q_z_x) reinterpret_cast<f32x4*>(log_q_z_x + b * K)[i] = sq[i];
-            if (log_p_z) reinterpret_cast<f32x4*>(log_p_z + b * K)[i] = sp[i];
+            if (stage & 2) {
+                if (log_q_z_x) {
+                    const f32x4 v = sq[i];
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(reinterpret_cast<f32x4*>(log_q_z_x + b * K) + i), "v"(v) : "memory");
+                }
+                if (log_p_z) {
+                    const f32x4 v = sp[i];
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(reinterpret_cast<f32x4*>(log_p_z + b * K) + i), "v"(v) : "memory");
+                }
+            } else {
+                if (log_q_z_x) reinterpret_cast<f32x4*>(log_q_z_x + b * K)[i] = sq[i];
+                if (log_p_z) reinterpret_cast<f32x4*>(log_p_z + b * K)[i] = sp[i];
+            }
         }
     }
     if (iw_ll) {
@@ -423,11 +469,19 @@ int lvae_launch_sample_iw(bool from_eps, const float* mu, const float* logvar, c
         // (16 KB), 16-byte aligned rows; LVAE_IW_NO_STAGE=1 for comparisons
         const bool al16 = (((uintptr_t)log_q_z_x | (uintptr_t)log_p_z) & 15) == 0;
         const int stage = ((log_q_z_x || log_p_z) && K % 4 == 0 && K >= 256 && K <= 2048 && al16 &&
-                           !sw.iw_no_stage) ? 1 : 0;
+                           !sw.iw_no_stage) ? (sw.iw_plain_stores ? 1 : 3) : 0;
         const size_t dyn = stage ? (size_t)2 * K * sizeof(float) : 0;
-#define LVAE_SIW2(E, UU, T, P)                                                                             \
-    hipLaunchKernelGGL((sample_iw_kernel<E, UU, T, P>), grid, dim3(T), dyn, st, mu, logvar, src, log_p_x_z, K, D, G, \
+        const int io = ((iw_ll && log_p_x_z) ? 1 : 0) | ((from_eps && z_out) ? 2 : 0);
+#define LVAE_SIW3(E, UU, T, P, I)                                                                             \
+    hipLaunchKernelGGL((sample_iw_kernel<E, UU, T, P, I>), grid, dim3(T), dyn, st, mu, logvar, src, log_p_x_z, K, D, G, \
                        z_out, log_q_z_x, log_p_z, iw_ll, stage)
+#define LVAE_SIW2(E, UU, T, P)                                                     \
+    do {                                                                           \
+        if (io == 0) LVAE_SIW3(E, UU, T, P, 0);                                    \
+        else if (io == 1) LVAE_SIW3(E, UU, T, P, 1);                               \
+        else if (io == 2) LVAE_SIW3(E, UU, T, P, (E ? 2 : 0));                     \
+        else LVAE_SIW3(E, UU, T, P, (E ? 3 : 1));                                  \
+    } while (0)
 #define LVAE_SIW(E, UU)                                                                             \
     do {                                                                                            \
         if (tpb == 64) { if (pipe) LVAE_SIW2(E, UU, 64, true); else LVAE_SIW2(E, UU, 64, false); }        \
@@ -442,6 +496,7 @@ int lvae_launch_sample_iw(bool from_eps, const float* mu, const float* logvar, c
             if (U == 8) LVAE_SIW(false, 8); else if (U == 4) LVAE_SIW(false, 4);
             else if (U == 2) LVAE_SIW(false, 2); else LVAE_SIW(false, 1);
         }
+#undef LVAE_SIW3
 #undef LVAE_SIW2
 #undef LVAE_SIW
     } else {
