@@ -223,6 +223,24 @@ int lvae_encode_tail_bwd_f32(const float* mu, const float* logvar, const float* 
                              const float* g_log_qz_mean, const float* g_prod_marg_mean, float* d_mu, float* d_logvar,
                              void* stream);
 
+/* The same tail and its backward for ANY training batch (modules/encoder.py:79-107; loss_and_optimisation.py:925-1018
+ * for the gradients): up to B = 32 the one-workgroup form above, beyond it B / 4 workgroups (a wave per sample, the
+ * other axis streamed through LDS; two launches forward, two backward, deterministic).  Same arguments as
+ * lvae_encode_tail_f32 / lvae_encode_tail_bwd_f32, plus `mode` (0: by size, 1: one workgroup, 2: multi-workgroup)
+ * and a caller-provided workspace of lvae_encode_tail_workspace_bytes(B, K, D) bytes (256-byte aligned; the backward
+ * uses it for the [B, B] softmax weights).  Envelope (lvae_encode_tail_ws_supported, host only, 1/0): D <= 64,
+ * B <= 4096, B * K * D <= 2^26, or the one-workgroup envelope; LVAE_ERR_UNSUPPORTED outside, LVAE_ERR_WORKSPACE when
+ * the multi-workgroup form is given too little. */
+int lvae_encode_tail_ws_supported(int64_t B, int64_t K, int D);
+int lvae_encode_tail_workspace_bytes(int64_t B, int64_t K, int D, int64_t* out_bytes);
+int lvae_encode_tail_ws_f32(const float* mu, const float* logvar, const float* eps, const float* prior_sample, int64_t B,
+                            int64_t K, int D, float log_norm, float* z, float* log_q_z_x, float* log_p_z, float* log_qz,
+                            float* log_qz_prod_marg, float* scalars, int mode, void* ws, int64_t ws_bytes, void* stream);
+int lvae_encode_tail_bwd_ws_f32(const float* mu, const float* logvar, const float* eps, int64_t B, int64_t K, int D,
+                                float log_norm, const float* g_z, const float* g_log_q_z_x, const float* g_log_p_z,
+                                const float* g_log_qz_mean, const float* g_prod_marg_mean, float* d_mu, float* d_logvar,
+                                int mode, void* ws, int64_t ws_bytes, void* stream);
+
 /* iw_log_p_x alone (loss_and_optimisation.py:783-794): three [B,K] inputs -> [B]. */
 int lvae_iw_lse_f32(const float* log_p_x_z, const float* log_p_z, const float* log_q_z_x, int64_t B,
                     int64_t K, float* out, void* stream);

@@ -45,6 +45,14 @@ _SIGNATURES = {
                                     _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p]),
     "lvae_encode_tail_bwd_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _i64, _int, _f32, _c_f32p, _c_f32p, _c_f32p,
                                         _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p]),
+    "lvae_encode_tail_ws_supported": (_int, [_i64, _i64, _int]),
+    "lvae_encode_tail_workspace_bytes": (_int, [_i64, _i64, _int, ctypes.POINTER(_i64)]),
+    "lvae_encode_tail_ws_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _i64, _int, _f32, _c_f32p, _c_f32p,
+                                       _c_f32p, _c_f32p, _c_f32p, _c_f32p, _int, ctypes.c_void_p, _i64,
+                                       ctypes.c_void_p]),
+    "lvae_encode_tail_bwd_ws_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _i64, _int, _f32, _c_f32p, _c_f32p,
+                                           _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _int, ctypes.c_void_p, _i64,
+                                           ctypes.c_void_p]),
     "lvae_iw_lse_f32": (_int, [_c_f32p, _c_f32p, _c_f32p, _i64, _i64, _c_f32p, ctypes.c_void_p]),
     "lvae_reduce_f32": (_int, [_c_f32p, _i64, _int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
                                _i64, ctypes.c_void_p]),

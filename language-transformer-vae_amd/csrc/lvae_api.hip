@@ -162,6 +162,15 @@ int lvae_launch_encode_tail_tiny(const float* mu, const float* logvar, const flo
 int lvae_launch_encode_tail_tiny_bwd(const float* mu, const float* logvar, const float* eps, int64_t B, int64_t K, int D,
                                      float log_norm, const float* g_z, const float* g_lqx, const float* g_lpz,
                                      const float* g_lq, const float* g_pm, float* d_mu, float* d_lv, hipStream_t st);
+bool lvae_encode_tail_mid_ok(int64_t B, int64_t K, int D);
+int64_t lvae_encode_tail_mid_workspace(int64_t B, int D);
+int lvae_launch_encode_tail_mid(const float* mu, const float* logvar, const float* eps, const float* prior, int64_t B,
+                                int64_t K, int D, float log_norm, float* z, float* log_q_z_x, float* log_p_z,
+                                float* log_qz, float* log_qz_pm, float* scalars, void* ws, hipStream_t st);
+int lvae_launch_encode_tail_mid_bwd(const float* mu, const float* logvar, const float* eps, int64_t B, int64_t K, int D,
+                                    float log_norm, const float* g_z, const float* g_lqx, const float* g_lpz,
+                                    const float* g_lq, const float* g_pm, float* d_mu, float* d_lv, void* ws,
+                                    hipStream_t st);
 bool lvae_pair_multi_supported(int DP, int epi);
 int lvae_launch_pair_multi(int DP, const PairJobs& jobs, int njobs, const PairHeader* hdr, bool excl, int epi,
                            hipStream_t st);
@@ -996,6 +1005,75 @@ extern "C" int lvae_encode_tail_bwd_f32(const float* mu, const float* logvar, co
                               (long long)B, (long long)K, D);
     return lvae_launch_encode_tail_tiny_bwd(mu, logvar, eps, B, K, D, log_norm, g_z, g_log_q_z_x, g_log_p_z,
                                             g_log_qz_mean, g_prod_marg_mean, d_mu, d_logvar, (hipStream_t)stream);
+}
+
+// ---- the same tail for any training batch: one workgroup up to B = LVAE_TAIL_ONE_WG_MAX, B / 4 workgroups beyond ----
+// mode: 0 = by size, 1 = the one-workgroup form (its envelope), 2 = the multi-workgroup form
+#define LVAE_TAIL_ONE_WG_MAX 32
+static int tail_form(int mode, int64_t B, int64_t K, int D) {      // 1 / 2, or 0: neither serves the shape
+    const bool t = lvae_encode_tail_tiny_ok(B, K, D), m = lvae_encode_tail_mid_ok(B, K, D);
+    if (mode == 1) return t ? 1 : 0;
+    if (mode == 2) return m ? 2 : 0;
+    if (t && (B <= LVAE_TAIL_ONE_WG_MAX || !m)) return 1;
+    return m ? 2 : 0;
+}
+
+extern "C" int lvae_encode_tail_ws_supported(int64_t B, int64_t K, int D) { return tail_form(0, B, K, D) ? 1 : 0; }
+
+extern "C" int lvae_encode_tail_workspace_bytes(int64_t B, int64_t K, int D, int64_t* out_bytes) {
+    LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
+    LVAE_CHECK_ARG(B >= 1 && K >= 1 && D >= 1, "need B, K, D >= 1");
+    *out_bytes = lvae_encode_tail_mid_ok(B, K, D) ? lvae_encode_tail_mid_workspace(B, D) : 0;
+    return LVAE_OK;
+}
+
+extern "C" int lvae_encode_tail_ws_f32(const float* mu, const float* logvar, const float* eps, const float* prior_sample,
+                                       int64_t B, int64_t K, int D, float log_norm, float* z, float* log_q_z_x,
+                                       float* log_p_z, float* log_qz, float* log_qz_prod_marg, float* scalars, int mode,
+                                       void* ws, int64_t ws_bytes, void* stream) {
+    LVAE_CHECK_ARG(mu && logvar && eps, "mu, logvar and eps must be non-NULL");
+    LVAE_CHECK_ARG(z || log_q_z_x || log_p_z || log_qz || log_qz_prod_marg || scalars, "no output requested");
+    LVAE_CHECK_ARG(mode >= 0 && mode <= 2, "mode must be 0 (by size), 1 (one workgroup) or 2 (multi-workgroup)");
+    LVAE_CHECK_ARG(B >= 1 && K >= 1 && D >= 1, "need B, K, D >= 1");
+    const int form = tail_form(mode, B, K, D);
+    if (form == 1)
+        return lvae_launch_encode_tail_tiny(mu, logvar, eps, prior_sample, B, K, D, log_norm, z, log_q_z_x, log_p_z,
+                                            log_qz, log_qz_prod_marg, scalars, (hipStream_t)stream);
+    if (form == 0)
+        return lvae_set_error(LVAE_ERR_UNSUPPORTED,
+                              "the fused encode tail serves D <= 64, B <= 4096, B * K * D <= 2^26 (one workgroup: B <= 128, "
+                              "B * D <= 4096, B * K * D <= 2^20); got B=%lld K=%lld D=%d mode=%d",
+                              (long long)B, (long long)K, D, mode);
+    const int64_t need = lvae_encode_tail_mid_workspace(B, D);
+    if (!ws || ws_bytes < need)
+        return lvae_set_error(LVAE_ERR_WORKSPACE, "encode tail: workspace of %lld bytes needed, %lld given",
+                              (long long)need, (long long)(ws ? ws_bytes : 0));
+    return lvae_launch_encode_tail_mid(mu, logvar, eps, prior_sample, B, K, D, log_norm, z, log_q_z_x, log_p_z, log_qz,
+                                       log_qz_prod_marg, scalars, ws, (hipStream_t)stream);
+}
+
+extern "C" int lvae_encode_tail_bwd_ws_f32(const float* mu, const float* logvar, const float* eps, int64_t B, int64_t K,
+                                           int D, float log_norm, const float* g_z, const float* g_log_q_z_x,
+                                           const float* g_log_p_z, const float* g_log_qz_mean,
+                                           const float* g_prod_marg_mean, float* d_mu, float* d_logvar, int mode,
+                                           void* ws, int64_t ws_bytes, void* stream) {
+    LVAE_CHECK_ARG(mu && logvar && eps, "mu, logvar and eps must be non-NULL");
+    LVAE_CHECK_ARG(d_mu || d_logvar, "at least one output gradient is required");
+    LVAE_CHECK_ARG(mode >= 0 && mode <= 2, "mode must be 0 (by size), 1 (one workgroup) or 2 (multi-workgroup)");
+    LVAE_CHECK_ARG(B >= 1 && K >= 1 && D >= 1, "need B, K, D >= 1");
+    const int form = tail_form(mode, B, K, D);
+    if (form == 1)
+        return lvae_launch_encode_tail_tiny_bwd(mu, logvar, eps, B, K, D, log_norm, g_z, g_log_q_z_x, g_log_p_z,
+                                                g_log_qz_mean, g_prod_marg_mean, d_mu, d_logvar, (hipStream_t)stream);
+    if (form == 0)
+        return lvae_set_error(LVAE_ERR_UNSUPPORTED, "outside the envelope of the fused encode tail (B=%lld K=%lld D=%d mode=%d)",
+                              (long long)B, (long long)K, D, mode);
+    const int64_t need = lvae_encode_tail_mid_workspace(B, D);
+    if (!ws || ws_bytes < need)
+        return lvae_set_error(LVAE_ERR_WORKSPACE, "encode tail backward: workspace of %lld bytes needed, %lld given",
+                              (long long)need, (long long)(ws ? ws_bytes : 0));
+    return lvae_launch_encode_tail_mid_bwd(mu, logvar, eps, B, K, D, log_norm, g_z, g_log_q_z_x, g_log_p_z, g_log_qz_mean,
+                                           g_prod_marg_mean, d_mu, d_logvar, ws, (hipStream_t)stream);
 }
 
 extern "C" int lvae_iw_lse_f32(const float* log_p_x_z, const float* log_p_z, const float* log_q_z_x,

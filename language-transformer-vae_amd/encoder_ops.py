@@ -37,9 +37,18 @@ class _Reparam(torch.autograd.Function):
         return d_mu, d_lv, None
 
 
-def _tiny_forward(mu, logvar, eps, prior_sample, log_norm, want_z=True):
-    """One launch (lvae_encode_tail_f32): z, log q(z|x), log p(z), and the scalars [mean log q(z), mean prod-marginals,
-    mmd]."""
+_TAIL_MODES = {None: 0, "auto": 0, True: 0, "one_wg": 1, "tiny": 1, "multi_wg": 2, "mid": 2}
+
+
+def _tail_workspace(B, K, D, dev):
+    nbytes = N._i64(0)
+    N.check(N.lib().lvae_encode_tail_workspace_bytes(int(B), int(K), int(D), nbytes))
+    return N.workspace(max(nbytes.value, 256), dev), nbytes.value
+
+
+def _tiny_forward(mu, logvar, eps, prior_sample, log_norm, want_z=True, mode=0):
+    """The fused tail (lvae_encode_tail_ws_f32: one workgroup up to B = 32, B / 4 workgroups beyond): z, log q(z|x),
+    log p(z), and the scalars [mean log q(z), mean prod-marginals, mmd]."""
     B, K, D = eps.shape
     dev = mu.device
     with torch.cuda.device(dev):
@@ -47,9 +56,10 @@ def _tiny_forward(mu, logvar, eps, prior_sample, log_norm, want_z=True):
         lqx = torch.empty(B, K, dtype=torch.float32, device=dev)
         lpz = torch.empty(B, K, dtype=torch.float32, device=dev)
         scal = torch.empty(3, dtype=torch.float32, device=dev)
-        N.check(N.lib().lvae_encode_tail_f32(N.ptr(mu), N.ptr(logvar), N.ptr(eps), N.ptr(prior_sample), B, K, D,
-                                             float(log_norm), N.ptr(z), N.ptr(lqx), N.ptr(lpz), None, None, N.ptr(scal),
-                                             N.stream_ptr(dev)))
+        ws, nbytes = _tail_workspace(B, K, D, dev)
+        N.check(N.lib().lvae_encode_tail_ws_f32(N.ptr(mu), N.ptr(logvar), N.ptr(eps), N.ptr(prior_sample), B, K, D,
+                                                float(log_norm), N.ptr(z), N.ptr(lqx), N.ptr(lpz), None, None,
+                                                N.ptr(scal), mode, N.ptr(ws), nbytes, N.stream_ptr(dev)))
     return z, lqx, lpz, scal
 
 
@@ -58,12 +68,13 @@ class _EncodeTailTiny(torch.autograd.Function):
     (lvae_encode_tail_f32), one backward (lvae_encode_tail_bwd_f32)."""
 
     @staticmethod
-    def forward(ctx, mu, logvar, eps, prior_sample, log_norm):
+    def forward(ctx, mu, logvar, eps, prior_sample, log_norm, mode=0):
         mu_d, lv_d = N.as_f32(mu.detach(), "mu"), N.as_f32(logvar.detach(), "logvar")
         eps_d, pr_d = N.as_f32(eps.detach(), "eps"), N.as_f32(prior_sample.detach(), "prior_sample")
-        z, lqx, lpz, scal = _tiny_forward(mu_d, lv_d, eps_d, pr_d, log_norm)
+        z, lqx, lpz, scal = _tiny_forward(mu_d, lv_d, eps_d, pr_d, log_norm, mode=mode)
         ctx.save_for_backward(mu_d, lv_d, eps_d)
         ctx.log_norm = float(log_norm)
+        ctx.mode = mode
         lq, pm, mmd = scal[0], scal[1], scal[2]
         ctx.mark_non_differentiable(mmd)              # quirk Q5: the reference's kernel detaches
         return z, lqx, lpz, lq, pm, mmd
@@ -80,15 +91,27 @@ class _EncodeTailTiny(torch.autograd.Function):
             d_mu = torch.empty_like(mu) if ctx.needs_input_grad[0] else None
             d_lv = torch.empty_like(logvar) if ctx.needs_input_grad[1] else None
             if d_mu is not None or d_lv is not None:
-                N.check(N.lib().lvae_encode_tail_bwd_f32(N.ptr(mu), N.ptr(logvar), N.ptr(eps), B, K, D, ctx.log_norm,
-                                                         N.ptr(g_z), N.ptr(g_lqx), N.ptr(g_lpz), N.ptr(g_lq),
-                                                         N.ptr(g_pm), N.ptr(d_mu), N.ptr(d_lv), N.stream_ptr(dev)))
-        return d_mu, d_lv, None, None, None
+                ws, nbytes = _tail_workspace(B, K, D, dev)
+                N.check(N.lib().lvae_encode_tail_bwd_ws_f32(N.ptr(mu), N.ptr(logvar), N.ptr(eps), B, K, D, ctx.log_norm,
+                                                            N.ptr(g_z), N.ptr(g_lqx), N.ptr(g_lpz), N.ptr(g_lq),
+                                                            N.ptr(g_pm), N.ptr(d_mu), N.ptr(d_lv), ctx.mode, N.ptr(ws),
+                                                            nbytes, N.stream_ptr(dev)))
+        return d_mu, d_lv, None, None, None, None
 
 
 def tiny_tail_supported(B, K, D):
-    """Whether the one-launch tail (csrc/encode_tail_tiny.hip) serves this batch: B <= 128, B * D <= 4096, ..."""
+    """Whether the one-workgroup tail (csrc/encode_tail_tiny.hip) serves this batch: B <= 128, B * D <= 4096, ..."""
     return bool(N.lib().lvae_encode_tail_supported(int(B), int(K), int(D)))
+
+
+def fused_tail_supported(B, K, D):
+    """Whether a fused tail serves this batch (one workgroup, or csrc/encode_tail_mid.hip: D <= 64, B <= 4096)."""
+    return bool(N.lib().lvae_encode_tail_ws_supported(int(B), int(K), int(D)))
+
+
+# Above this batch size the general kernels (matrix cores) take over from the fused multi-workgroup tail, whose pair
+# loops are plain vector code (tools/bench_train_tail.py)
+FUSED_TAIL_MAX_B = 1024
 
 
 def reparameterize(mu, logvar, n_samples=1, eps=None):
@@ -123,25 +146,27 @@ def encode_tail(mu, logvar, n_samples=1, dataset_size=10000, return_log_q_z_x=Tr
     (modules/encoder.py:79-128): sample, per-sample densities, the Chen et al. minibatch estimate of
     log q(z) / prod-marginals on the first sample (quirk Q4: dataset_size defaults to 10000, :68), and
     the biased MMD of the first sample against the prior.
-    ``fused`` (default: whenever the batch fits, i.e. the training-time batch sizes): everything in ONE launch, and
-    one more for the backward (lvae_encode_tail_f32 / _bwd_f32); ``fused=False`` forces the general kernels."""
+    ``fused`` (default: the training-time batch sizes, B <= 1024 at D <= 64): everything in one or two launches, and
+    as many for the backward (lvae_encode_tail_ws_f32 / _bwd_ws_f32: one workgroup up to B = 32, B / 4 workgroups
+    beyond); "one_wg" / "multi_wg" force a form; ``fused=False`` forces the general kernels."""
     import math
     B, D = mu.shape
     if eps is None:
         eps = torch.zeros(B, n_samples, D, dtype=torch.float32, device=mu.device).normal_()
     if fused is None:
-        fused = mu.is_cuda and tiny_tail_supported(B, eps.shape[1], D)
+        fused = mu.is_cuda and B <= FUSED_TAIL_MAX_B and fused_tail_supported(B, eps.shape[1], D)
+    mode = _TAIL_MODES[fused] if fused is not False else 0
     if fused:
         if prior_sample is None:
             prior_sample = torch.randn(B, D, dtype=torch.float32, device=mu.device)        # :53, randn_like(latent_z)
         log_norm = math.log(B * dataset_size)                                                 # "chen", :207
         if E._needs_grad(mu, logvar):
             latent_z, log_q_z_x, log_p_z, log_q_z, log_q_z_prod_marg, mmd_loss = _EncodeTailTiny.apply(
-                mu, logvar, eps, prior_sample, log_norm)
+                mu, logvar, eps, prior_sample, log_norm, mode)
         else:
             mu, logvar = N.as_f32(mu, "mu"), N.as_f32(logvar, "logvar")
             latent_z, log_q_z_x, log_p_z, scal = _tiny_forward(mu, logvar, N.as_f32(eps, "eps"),
-                                                               N.as_f32(prior_sample, "prior_sample"), log_norm)
+                                                               N.as_f32(prior_sample, "prior_sample"), log_norm, mode=mode)
             log_q_z, log_q_z_prod_marg, mmd_loss = scal[0], scal[1], scal[2]
         return {"mu": mu, "logvar": logvar, "latent_z": latent_z, "mmd_loss": mmd_loss,
                 "log_q_z": log_q_z if return_log_q_z else None,

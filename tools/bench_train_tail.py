@@ -41,24 +41,30 @@ def timeit(fn, mu, logvar, eps, iters=50):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / iters * 1e6
 
-for B in (32, 64, 128, 512, 2048):
+def fwd_only(mu, logvar, eps, fused):
+    with torch.no_grad():
+        f = lambda: EO.encode_tail(mu, logvar, n_samples=1, dataset_size=10000, eps=eps, fused=fused)
+        for _ in range(5): f()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(50): f()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 50 * 1e6
+
+for B in (32, 64, 128, 256, 512, 1024, 2048, 4096):
     g = torch.Generator(device="cuda").manual_seed(B)
     mu = torch.randn(B, 32, device="cuda", generator=g).requires_grad_(True)
     logvar = (0.5 * torch.randn(B, 32, device="cuda", generator=g) - 1).requires_grad_(True)
     eps = torch.randn(B, 1, 32, device="cuda", generator=g)
-    FUSED[0] = None          # default routing: the one-launch kernels whenever the batch fits
-    a = timeit(hip_tail, mu, logvar, eps)
-    ga = mu.grad.clone()
-    FUSED[0] = False         # the general kernel chain
-    c = timeit(hip_tail, mu, logvar, eps)
+    line = f"B={B}:"
+    ref_grad = None
+    for name, fused in (("default", None), ("one_wg", "one_wg"), ("multi_wg", "multi_wg"), ("general", False)):
+        if fused == "one_wg" and not EO.tiny_tail_supported(B, 1, 32):
+            continue
+        FUSED[0] = fused
+        t = timeit(hip_tail, mu, logvar, eps)
+        if ref_grad is None:
+            ref_grad = mu.grad.clone()
+        err = float((ref_grad - mu.grad).abs().max() / mu.grad.abs().max())
+        line += f"  {name} fwd+bwd {t:.0f} us, fwd only {fwd_only(mu, logvar, eps, fused):.0f} us (grad diff {err:.0e})"
     b = timeit(eager_tail, mu, logvar, eps)
-    err = float((ga - mu.grad).abs().max() / mu.grad.abs().max())
-    with torch.no_grad():
-        FUSED[0] = None
-        f = lambda: EO.encode_tail(mu, logvar, n_samples=1, dataset_size=10000, eps=eps)
-        for _ in range(5): f()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(50): f()
-        torch.cuda.synchronize(); fw = (time.perf_counter() - t0) / 50 * 1e6
-    print(f"B={B}: HIP fwd+bwd {a:.0f} us (one-launch tail: {EO.tiny_tail_supported(B, 1, 32)}; general kernels {c:.0f} us; "
-          f"forward only, no grad {fw:.0f} us)   PyTorch eager (GPU) {b:.0f} us   grad rel diff {err:.1e}", flush=True)
+    print(line + f"   PyTorch eager (GPU) {b:.0f} us", flush=True)
