@@ -35,6 +35,10 @@ step "PMC SQ + clock of the split-bf16 pair kernel"
 timeout -s KILL 150 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_bf16x3" -o p -- python3 $R/tools/run_path.py 3 65536 32 20 > "$OUT/pmc_bf16x3.log" 2>&1 || exit 1
 step "kernel trace of the matrix-core backward"
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_bwd" -o p -- python3 $R/tools/bench_bwd.py 16384,16384,32 16384,16384,64 16384,16384,128 65536,65536,32 > "$OUT/bwd.log" 2>&1 || exit 1
+step "kernel trace of the IW call at C5, one form per run (the reduction alone, with the two density matrices, with z)"
+for form in iw dens z; do
+timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_iw_c5_$form" -o p -- python3 $R/tools/bench_iw.py 16384,1000,32 only=$form > "$OUT/iw_c5_$form.log" 2>&1 || exit 1
+done
 step "IW, small problems, training tail (no trace)"
 timeout -k 10 200 python3 $R/tools/bench_iw.py > "$OUT/iw.log" 2>&1 || exit 1
 timeout -k 10 200 python3 $R/tools/bench_small.py > "$OUT/small.log" 2>&1 || exit 1

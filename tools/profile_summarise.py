@@ -15,12 +15,16 @@ def first(pattern):
 for name, out in (("trace_bench", "kernel_stats_bench_n1.csv"), ("trace_paths", "kernel_stats_secondary_paths.csv"),
                   ("trace_pm", "kernel_stats_prod_marginals_c2.csv"),
                   ("trace_pm_bx", "kernel_stats_prod_marginals_c2_bf16x3.csv"), ("trace_perm", "kernel_stats_mmd_perm_c4.csv"),
-                  ("trace_bf16x3", "kernel_stats_bf16x3_comparison.csv"), ("trace_bwd", "kernel_stats_backward.csv")):
+                  ("trace_bf16x3", "kernel_stats_bf16x3_comparison.csv"), ("trace_bwd", "kernel_stats_backward.csv"),
+                  ("trace_iw_c5_iw", "kernel_stats_iw_c5_reduction_only.csv"),
+                  ("trace_iw_c5_dens", "kernel_stats_iw_c5_with_densities.csv"),
+                  ("trace_iw_c5_z", "kernel_stats_iw_c5_with_z.csv")):
     f = first(f"{name}/**/*kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(dst, out))
 texts = []
-for log in ("paths.log", "pm.log", "pm_bx.log", "perm.log", "bf16x3.log", "bwd.log", "iw.log", "small.log", "train_tail.log"):
+for log in ("paths.log", "pm.log", "pm_bx.log", "perm.log", "bf16x3.log", "bwd.log", "iw.log", "iw_c5_iw.log", "iw_c5_dens.log",
+            "iw_c5_z.log", "small.log", "train_tail.log"):
     p = os.path.join(src, log)
     if os.path.exists(p):
         texts += [f"## {log}"] + [l.rstrip() for l in open(p) if not l.startswith(("W2", "E2", "I2")) and "amdgpu.ids" not in l]
