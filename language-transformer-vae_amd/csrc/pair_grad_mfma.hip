@@ -37,7 +37,11 @@
 #define BWD_TAIL_PIECES(DP) (((DP) / 8 + 2 + 1) / 2)
 #define BWD_BX(DP) ((DP) <= 32)
 #define BWD_FEAT_F(DP) (BWD_BX(DP) ? ((DP) / 16) * 6 * 256 : 64 * (DP))
-#define BWD_TAIL_OFF(DP) (64 * (DP) + BWD_FEAT_F(DP))
+// ... and so is the density operand: (DP / 8) steps of eight dimensions x 3 limbs pieces of 1 KiB for a streamed block,
+// [row][k-half][step][limb][8] bf16 (3 DP floats' worth per row) for a kept element
+#define BWD_DENS_F(DP) (BWD_BX(DP) ? ((DP) / 8) * 3 * 256 : 64 * (DP))
+#define BWD_COL_F(DP) (BWD_BX(DP) ? 3 * (DP) : 2 * (DP))
+#define BWD_TAIL_OFF(DP) (BWD_DENS_F(DP) + BWD_FEAT_F(DP))
 #define BWD_REC_F(DP) (BWD_TAIL_OFF(DP) + 64 * BWD_TAIL_PIECES(DP))
 
 typedef __bf16 bwd_bf16x8 __attribute__((ext_vector_type(8)));
@@ -122,7 +126,7 @@ bwd_prep_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, 
         if (c > cond_floor) atomicMax(&hdr->cond_bits, __float_as_uint(c));
     }
     float* __restrict__ rec = (post ? rec_j : rec_i) + blk * (int64_t)BWD_REC_F(DP);
-    float* __restrict__ cop = (post ? colop_j : colop_i) + blk * 32 * (int64_t)(2 * DP);
+    float* __restrict__ cop = (post ? colop_j : colop_i) + blk * 32 * (int64_t)BWD_COL_F(DP);
     float* __restrict__ cb = (post ? colbias_j : colbias_i) + blk * 32;
     // density operand, term h of dimension s
     auto dens = [&](int row, int h, int s) -> float {
@@ -133,9 +137,33 @@ bwd_prep_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, 
         }
         return h == 0 ? v : v * v;
     };
+    auto limbs3 = [](float o, unsigned short& h16, unsigned short& m16, unsigned short& l16) {
+        const __bf16 hb = (__bf16)o;
+        const float r1 = o - (float)hb;
+        const __bf16 mb = (__bf16)r1;
+        const __bf16 lb = (__bf16)(r1 - (float)mb);
+        h16 = __builtin_bit_cast(unsigned short, hb);
+        m16 = __builtin_bit_cast(unsigned short, mb);
+        l16 = __builtin_bit_cast(unsigned short, lb);
+    };
+    if (BWD_BX(DP)) {
+        // A operand of the density contraction on the bf16 pipe: piece (step * 3 + limb) holds, for lane row + 32 h, the
+        // eight dimensions 8 step .. 8 step + 7 of term h (one MFMA step = one group of eight dimensions)
+        unsigned short* dr = reinterpret_cast<unsigned short*>(rec);
+        for (int idx = tid; idx < (DP / 8) * 512; idx += 256) {
+            const int i = idx & 7, lane = (idx >> 3) & 63, step = idx >> 9;
+            unsigned short a, b, c;
+            limbs3(dens(lane & 31, lane >> 5, 8 * step + i), a, b, c);
+            const int pb = (step * 3) * 512 + lane * 8 + i;
+            dr[pb] = a;
+            dr[pb + 512] = b;
+            dr[pb + 1024] = c;
+        }
+    } else {
     for (int idx = tid; idx < 64 * DP; idx += 256) {       // A operand of the density contraction: [s/4][h][row][s%4] (16 B per lane, lane = row + 32 h)
         const int e = idx & 3, row = (idx >> 2) & 31, h = (idx >> 7) & 1, sg = idx >> 8;     // slot = lane = row + 32 h
         rec[idx] = dens(row, h, 4 * sg + e);
+    }
     }
     auto feat = [&](int row, int f) -> float {
         const int half = f >= DP, d = f - half * DP;
@@ -147,34 +175,37 @@ bwd_prep_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, 
         // A operand of the feature contraction on the bf16 pipe: piece ((t * 2 + s) * 3 + limb) holds, for lane
         // (f % 32) + 32 h, the eight k-entries i of k-group s -- streamed row 16 s + 8 (i / 4) + 4 h + (i % 4), the row
         // that register 8 s + i of a 32x32 fp32 accumulator holds on half-wave h
-        unsigned short* fr = reinterpret_cast<unsigned short*>(rec + 64 * DP);
+        unsigned short* fr = reinterpret_cast<unsigned short*>(rec + BWD_DENS_F(DP));
         for (int idx = tid; idx < (DP / 16) * 2 * 512; idx += 256) {
             const int i = idx & 7, lane = (idx >> 3) & 63, s2 = (idx >> 9) & 1, t = idx >> 10;
             const int fl = lane & 31, h = lane >> 5;
             const int row = 16 * s2 + 8 * (i >> 2) + 4 * h + (i & 3);
-            const float o = feat(row, 32 * t + fl);
-            const __bf16 hb = (__bf16)o;
-            const float r1 = o - (float)hb;
-            const __bf16 mb = (__bf16)r1;
-            const __bf16 lb = (__bf16)(r1 - (float)mb);
             const int pbase = ((t * 2 + s2) * 3) * 512 + lane * 8 + i;
-            fr[pbase] = __builtin_bit_cast(unsigned short, hb);
-            fr[pbase + 512] = __builtin_bit_cast(unsigned short, mb);
-            fr[pbase + 1024] = __builtin_bit_cast(unsigned short, lb);
+            limbs3(feat(row, 32 * t + fl), fr[pbase], fr[pbase + 512], fr[pbase + 1024]);
         }
     } else {
         for (int idx = tid; idx < 64 * DP; idx += 256) {       // A operand of the feature contraction: [f/32][q][h][f%32][e]
             const int e = idx & 3, fl = (idx >> 2) & 31, h = (idx >> 7) & 1, q = (idx >> 8) & 3, ft = idx >> 10;
-            rec[64 * DP + idx] = feat(8 * q + 4 * h + e, ft * 32 + fl);
+            rec[BWD_DENS_F(DP) + idx] = feat(8 * q + 4 * h + e, ft * 32 + fl);
         }
     }
     const int toff = BWD_TAIL_OFF(DP);
     for (int idx = tid; idx < 32 * G; idx += 256) rec[toff + idx] = sm_gb[idx];
     if (tid < 32) rec[toff + 32 * G + tid] = sm_bias[tid];
     else if (tid < 64) rec[toff + 32 * G + tid] = sm_g[tid - 32];
+    if (BWD_BX(DP)) {                                       // kept-axis rows [row][h][step][limb][8] bf16
+        unsigned short* cr = reinterpret_cast<unsigned short*>(cop);
+        const int NSTEP = DP / 8;
+        for (int idx = tid; idx < 64 * DP; idx += 256) {
+            const int i = idx & 7, step = (idx >> 3) % NSTEP, h = ((idx >> 3) / NSTEP) & 1, row = (idx >> 3) / (2 * NSTEP);
+            const int pb = (((row * 2 + h) * NSTEP + step) * 3) * 8 + i;
+            limbs3(dens(row, h, 8 * step + i), cr[pb], cr[pb + 8], cr[pb + 16]);
+        }
+    } else {
     for (int idx = tid; idx < 64 * DP; idx += 256) {       // kept-axis rows [row][h][s]
         const int s = idx % DP, h = (idx / DP) & 1, row = idx / (2 * DP);
         cop[idx] = dens(row, h, s);
+    }
     }
     if (tid < 32) cb[tid] = sm_bias[tid];
     if (post)       // as a kept element the posterior brings its group biases itself: [row][G]
@@ -200,8 +231,16 @@ pair_bwd_mfma_kernel(const float* __restrict__ rec, const float* __restrict__ co
     const int r = lane & 31, h = lane >> 5;
     const int64_t col = ((int64_t)blockIdx.x * 4 + wave) * 32 + r;
 
-    float bc[DP];
-    {
+    constexpr int NS = DP / 8;                   // BX: MFMA steps (= groups of eight dimensions) per tile
+    float bc[BX ? 1 : DP];
+    bwd_bf16x8 bzx[BX ? NS : 1][3];              // BX: [step][limb]
+    if constexpr (BX) {
+        const uint4* src = reinterpret_cast<const uint4*>(colop) + (col * 2 + h) * NS * 3;
+#pragma unroll
+        for (int sx = 0; sx < NS; ++sx)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) bzx[sx][l] = __builtin_bit_cast(bwd_bf16x8, src[sx * 3 + l]);
+    } else {
         const f32x4* src = reinterpret_cast<const f32x4*>(colop + (col * 2 + h) * DP);
 #pragma unroll
         for (int q = 0; q < DP / 4; ++q) {
@@ -210,6 +249,8 @@ pair_bwd_mfma_kernel(const float* __restrict__ rec, const float* __restrict__ co
             for (int e = 0; e < 4; ++e) bc[4 * q + e] = v[e];
         }
     }
+    constexpr int LA[6] = {1, 2, 0, 1, 0, 0};     // limb of the streamed operand (A), smallest products first
+    constexpr int LB[6] = {1, 0, 2, 0, 1, 0};     // limb of the resident operand (B)
     const float cb = colbias[col];
     // ROWG: the kept posterior's group biases (the streamed samples have none) enter a chain as one more MFMA step,
     // ones x (bias in k-half 0, zero in k-half 1): no per-group accumulator images in registers, no vector adds
@@ -273,11 +314,22 @@ pair_bwd_mfma_kernel(const float* __restrict__ rec, const float* __restrict__ co
                     for (int e = 0; e < 4; ++e) acc[4 * q + e] = b4[e];
                 }
             }
+            if constexpr (BX) {
+                // one step of v_mfma_f32_32x32x16_bf16 = this group's eight dimensions, both terms; six limb products
+                const uint4* dr = reinterpret_cast<const uint4*>(st) + lane;
+                bwd_bf16x8 da[3];
+#pragma unroll
+                for (int l = 0; l < 3; ++l) da[l] = __builtin_bit_cast(bwd_bf16x8, dr[(gi * 3 + l) * 64]);
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[LA[pr]], bzx[gi][LB[pr]], acc, 0, 0, 0);
+            } else {
 #pragma unroll
             for (int sg = 2 * gi; sg < 2 * gi + 2; ++sg) {
                 const f32x4 a4 = *reinterpret_cast<const f32x4*>(st + (sg * 64 + lane) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], bc[4 * sg + e], acc, 0, 0, 0);
+            }
             }
             if (gi == 0) tot = acc;
             else tot += acc;
@@ -324,9 +376,7 @@ pair_bwd_mfma_kernel(const float* __restrict__ rec, const float* __restrict__ co
                     wl[s2][2][2 * pr] = ll[0];
                     wl[s2][2][2 * pr + 1] = ll[1];
                 }
-            constexpr int LA[6] = {1, 2, 0, 1, 0, 0};     // limb of the features (A), smallest products first
-            constexpr int LB[6] = {1, 0, 2, 0, 1, 0};     // limb of the weights (B)
-            const uint4* fr = reinterpret_cast<const uint4*>(st + 64 * DP) + lane;
+            const uint4* fr = reinterpret_cast<const uint4*>(st + BWD_DENS_F(DP)) + lane;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -344,7 +394,7 @@ pair_bwd_mfma_kernel(const float* __restrict__ rec, const float* __restrict__ co
             f32x4 f4[NFT];
 #pragma unroll
             for (int t = 0; t < NFT; ++t)
-                f4[t] = *reinterpret_cast<const f32x4*>(st + 64 * DP + ((t * 4 + q) * 64 + lane) * 4);
+                f4[t] = *reinterpret_cast<const f32x4*>(st + BWD_DENS_F(DP) + ((t * 4 + q) * 64 + lane) * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -463,8 +513,8 @@ BwdMfmaLayout lvae_bwd_mfma_layout(int64_t M, int64_t N, int D) {
     size_t o = 0;
     L.off_recj = o;  o = lvae_align256(o + (size_t)(L.cpad_j / 32) * rec);
     L.off_reci = o;  o = lvae_align256(o + (size_t)(L.cpad_i / 32) * rec);
-    L.off_colj = o;  o = lvae_align256(o + (size_t)L.cpad_j * 2 * L.DP * sizeof(float));
-    L.off_coli = o;  o = lvae_align256(o + (size_t)L.cpad_i * 2 * L.DP * sizeof(float));
+    L.off_colj = o;  o = lvae_align256(o + (size_t)L.cpad_j * BWD_COL_F(L.DP) * sizeof(float));
+    L.off_coli = o;  o = lvae_align256(o + (size_t)L.cpad_i * BWD_COL_F(L.DP) * sizeof(float));
     L.off_cbj = o;   o = lvae_align256(o + (size_t)L.cpad_j * sizeof(float));
     L.off_cbi = o;   o = lvae_align256(o + (size_t)L.cpad_i * sizeof(float));
     L.off_pa = o;    o = lvae_align256(o + (size_t)L.ns_a * L.cpad_i * 2 * L.DP * sizeof(float));
