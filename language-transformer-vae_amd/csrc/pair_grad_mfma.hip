@@ -35,7 +35,11 @@
 // BX (D <= 32): the features are stored as three bf16 limbs each, in the fragment order of v_mfma_f32_32x32x16_bf16
 // (see the sweep kernel): (DP / 16) feature tiles x 2 k-groups x 3 limbs pieces of 1 KiB.
 #define BWD_TAIL_PIECES(DP) (((DP) / 8 + 2 + 1) / 2)
+#ifdef BWD_FORCE_FP32
+#define BWD_BX(DP) (false && (DP) > 0)
+#else
 #define BWD_BX(DP) ((DP) <= 32)
+#endif
 #define BWD_FEAT_F(DP) (BWD_BX(DP) ? ((DP) / 16) * 6 * 256 : 64 * (DP))
 // ... and so is the density operand: (DP / 8) steps of eight dimensions x 3 limbs pieces of 1 KiB for a streamed block,
 // [row][k-half][step][limb][8] bf16 (3 DP floats' worth per row) for a kept element
@@ -320,9 +324,14 @@ pair_bwd_mfma_kernel(const float* __restrict__ rec, const float* __restrict__ co
                 bwd_bf16x8 da[3];
 #pragma unroll
                 for (int l = 0; l < 3; ++l) da[l] = __builtin_bit_cast(bwd_bf16x8, dr[(gi * 3 + l) * 64]);
+                // The limb products are accumulated in the same (posterior limb, sample limb) order in both sweeps -- the
+                // streamed and the resident operand swap roles between them --, so that v_ij comes out bit-identical in
+                // A and in B: sweep B's weights are normalised by the sums of sweep A, and the rounding of a far sample's
+                // |v| ~ 1e4 only cancels if both sweeps made the same one (fuzz case: 4e-4 instead of 9e-7 otherwise).
 #pragma unroll
                 for (int pr = 0; pr < 6; ++pr)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[LA[pr]], bzx[gi][LB[pr]], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ROWG ? LB[pr] : LA[pr]], bzx[gi][ROWG ? LA[pr] : LB[pr]],
+                                                                  acc, 0, 0, 0);
             } else {
 #pragma unroll
             for (int sg = 2 * gi; sg < 2 * gi + 2; ++sg) {
