@@ -51,8 +51,8 @@ prep_bf16x3_kernel(const float* __restrict__ x, const float* __restrict__ spread
             float v = 0.f;
             if (d < D) {
                 const float xs = x[row * D + d] - (LIN ? 0.f : (float)(hdr->colsum[d] * inv_ngauss));
-                if (LIN) {
-                    v = SRC == 3 ? -2.0f * xs : xs;
+                if (LIN) {      // (the polynomial epilogues' scale is folded into the POINT rows: prep.hip, prep_rows)
+                    v = SRC == 3 ? (-2.0f * (hdr->ksum.poly ? -hdr->ksum.nbase : 1.f)) * xs : xs;
                 } else if (GAUSS) {
                     const float sp = spread[row * D + d];
                     const float p = spread_kind == LVAE_SPREAD_VAR ? 1.0f / sp : expf(-sp);

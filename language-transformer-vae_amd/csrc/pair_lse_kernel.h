@@ -300,12 +300,11 @@ pair_lse_body(const float* __restrict__ rfrag, const float* __restrict__ rbias,
     // are this case.
     constexpr int KC = EPI == 1 ? 2 : (EPI == 2 ? 17 : (EPI == 3 ? LVAE_KSUM_MAX : (EPI == 5 ? 7 : 1)));
     float kc[KC];
-    float k_eps = 0.f, k_nbase = 0.f;
+    float k_eps = 0.f;
     int k_n = 0;
     if (KS) {
         const KsumParams* kp = &hdr->ksum;
         k_eps = kp->eps;
-        k_nbase = kp->nbase;
         k_n = kp->n;
 #pragma unroll
         for (int k = 0; k < KC; ++k) kc[k] = EPI == 5 ? kp->c[2 * k + 1] : kp->c[k];
@@ -317,15 +316,16 @@ pair_lse_body(const float* __restrict__ rfrag, const float* __restrict__ rbias,
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) cn[cb] = KS ? colnorm[col0 + cb * 32 + r] : 0.f;
     // two kernel values at a time (packed fp32 for the polynomial)
-    const float k_ne = k_nbase * k_eps;
     auto kfun2 = [&](float d2a, float d2b, float cnv) -> f32x2 {
         if (EPI == 1 || EPI == 2 || EPI == 5) {
-            // exponent -base * (|d2 + |x|^2| + eps) in three instructions per pair of values: one packed add, then
-            // one fma each with the absolute value as an input modifier
+            // The operands of these epilogues arrive scaled (prep_rows: base log2e folded into the POINT rows, the
+            // biases and the column norms, eps into the biases), so the contraction plus the column norm IS the
+            // exponent up to sign: one packed add per pair of values, then v_exp_f32 with the negated absolute value
+            // as an input modifier -- no multiply-add in front of the exponential
             const f32x2 x = (f32x2){d2a, d2b} + (f32x2){cnv, cnv};
             f32x2 t;
-            t.x = lvae_exp2(__builtin_fmaf(__builtin_fabsf(x.x), k_nbase, k_ne));
-            t.y = lvae_exp2(__builtin_fmaf(__builtin_fabsf(x.y), k_nbase, k_ne));
+            t.x = lvae_exp2(-__builtin_fabsf(x.x));
+            t.y = lvae_exp2(-__builtin_fabsf(x.y));
             if (EPI == 1) return __builtin_elementwise_fma((f32x2){kc[1], kc[1]}, t, (f32x2){kc[0], kc[0]});
             if (EPI == 5) {
                 const f32x2 t2 = t * t;

@@ -105,6 +105,13 @@ prep_rows(const int64_t wg, const int rb, const float* __restrict__ x, const flo
     __shared__ float sm_w[16][3];
     const int NQ = DP >> 2;                    // 4, 8, 16 or 32 lanes per row
     const int tid = threadIdx.x;
+    // Kernel sums with a polynomial epilogue (one exponential per pair, t = exp2(-base log2e (eps + |d2|))): the scale
+    // base log2e is folded into the operands and eps into the row bias, so that the contraction delivers the exponent
+    // itself and the epilogue is exp2(-|acc + |x|^2|) with no multiply-add in front of it (the header's parameters are
+    // set before any operand is prepared)
+    const float lin_s = (LIN && hdr->ksum.poly) ? -hdr->ksum.nbase : 1.f;
+    const float lin_e = (LIN && hdr->ksum.poly) ? hdr->ksum.eps : 0.f;
+    const float lin_m = SRC == 3 ? -2.0f * lin_s : 1.f;
     if (!LIN && tid < DP) sm_shift[tid] = tid < D ? (float)(hdr->colsum[tid] * inv_ngauss) : 0.f;
     __syncthreads();
     const int r = tid / NQ;
@@ -134,8 +141,8 @@ prep_rows(const int64_t wg, const int rb, const float* __restrict__ x, const flo
                 for (int e = 0; e < 4; ++e) {
                     const float x0 = xr[2 * e];
                     const float x1 = xr[2 * e + 1];
-                    v0[e] = SRC == 3 ? -2.0f * x0 : x0;
-                    v1[e] = SRC == 3 ? -2.0f * x1 : x1;
+                    v0[e] = lin_m * x0;
+                    v1[e] = lin_m * x1;
                     csum += x0 * x0 + x1 * x1;
                 }
             }
@@ -209,7 +216,8 @@ prep_rows(const int64_t wg, const int rb, const float* __restrict__ x, const flo
             if (LIN && valid && q == 0 && cond_floor >= 0.f && csum > cond_floor)
                 atomicMax(&hdr->cond_bits, __float_as_uint(csum));
             if (bias && q == 0 && row < npad) {
-                float bv = GAUSS ? -0.5f * LVAE_LOG2E * csum : ((POINT || LIN) ? csum : 0.f);
+                float bv = GAUSS ? -0.5f * LVAE_LOG2E * csum
+                                 : (LIN ? (csum + (SRC == 3 ? lin_e : 0.f)) * lin_s : (POINT ? csum : 0.f));
                 if (!valid) bv = FRAG ? ((POINT || LIN) ? INFINITY : -INFINITY) : 0.f;
                 bias[row] = bv;
             }
