@@ -56,8 +56,8 @@ def test_matrix_core_backward_vs_float64_autograd(M, N, D, lvae_env):
     _check(_our_grads(mu, lv, z, a), _reference_grads(mu, lv, z, a, math.log(N)))
 
 
-@pytest.mark.parametrize("D", [31, 16, 64])
-def test_far_samples_keep_normalised_weights(D, lvae_env):
+@pytest.mark.parametrize("D,tol", [(31, 1e-4), (16, 1e-4), (64, 3e-4)])      # (D = 64: fp32 contractions; a far sample's
+def test_far_samples_keep_normalised_weights(D, tol, lvae_env):               #  |v| ~ 2e4 costs d_z one ulp of it: 1.2e-4)
     """Samples far from every posterior (|v| ~ 1e4): their weights only come out right because sweep B evaluates v_ij
     bit-identically to sweep A, whose sums normalise them -- with the bf16-limb contraction (D <= 32) that needs the limb
     products accumulated in the same order in both sweeps (4e-4 on d_mu otherwise, 1e-6 with it)."""
@@ -66,7 +66,7 @@ def test_far_samples_keep_normalised_weights(D, lvae_env):
     mu, lv, z, a = _problem(17, M, N, D, sigma_scale=0.3)
     z = z.clone()
     z[: M // 7] += 6.0
-    _check(_our_grads(mu, lv, z, a), _reference_grads(mu, lv, z, a, math.log(N), chunk=64), tol=1e-4)
+    _check(_our_grads(mu, lv, z, a), _reference_grads(mu, lv, z, a, math.log(N), chunk=64), tol=tol)
 
 
 @pytest.mark.parametrize("case", ["b32", "ragged_d20", "d64", "n300", "d100", "d128"])
