@@ -90,6 +90,37 @@ def test_argument_validation_and_error_text():
     assert rc == -4 and b"D <= 128" in lib.lvae_last_error()
 
 
+def test_encode_tail_entry_points_validate_on_the_host():
+    """lvae_encode_tail_ws_f32 / _bwd_ws_f32: envelope, form selection, workspace size -- all decided before a launch."""
+    from lvae import _native as N
+    lib = N.lib()
+    out = ctypes.c_int64(0)
+    # one workgroup up to B = 128 (B * D <= 4096), the multi-workgroup form up to B = 4096 at D <= 64
+    assert lib.lvae_encode_tail_supported(32, 1, 32) == 1 and lib.lvae_encode_tail_supported(256, 1, 32) == 0
+    assert lib.lvae_encode_tail_ws_supported(256, 1, 32) == 1 and lib.lvae_encode_tail_ws_supported(4096, 1, 64) == 1
+    assert lib.lvae_encode_tail_ws_supported(4097, 1, 32) == 0 and lib.lvae_encode_tail_ws_supported(256, 1, 65) == 0
+    assert lib.lvae_encode_tail_ws_supported(16, 1, 200) == 1            # wide latents: the one-workgroup form only
+    assert lib.lvae_encode_tail_workspace_bytes(512, 1, 32, out) == 0
+    need = out.value
+    assert need >= 512 * 512 * 4 + 3 * 512 * 32 * 4 and need % 256 == 0  # the [B, B] weights + three [B, D] arrays
+    assert lib.lvae_encode_tail_workspace_bytes(16, 1, 200, out) == 0 and out.value == 0
+    assert lib.lvae_encode_tail_workspace_bytes(0, 1, 32, out) == -1
+    dummy = ctypes.c_void_p(256)
+    args = (dummy, dummy, dummy, dummy, 512, 1, 32, 0.0, dummy, dummy, dummy, None, None, dummy)
+    assert lib.lvae_encode_tail_ws_f32(*args, 0, dummy, need - 1, None) == -2 and b"workspace" in lib.lvae_last_error()
+    assert lib.lvae_encode_tail_ws_f32(*args, 0, None, 0, None) == -2
+    assert lib.lvae_encode_tail_ws_f32(*args, 3, dummy, need, None) == -1 and b"mode" in lib.lvae_last_error()
+    assert lib.lvae_encode_tail_ws_f32(*args, 1, dummy, need, None) == -4         # B = 512 is outside the one-workgroup form
+    wide = (dummy, dummy, dummy, dummy, 16, 1, 200, 0.0, dummy, dummy, dummy, None, None, dummy)
+    assert lib.lvae_encode_tail_ws_f32(*wide, 2, dummy, 1 << 30, None) == -4      # ... and D = 200 outside the other
+    assert lib.lvae_encode_tail_ws_f32(None, dummy, dummy, dummy, 512, 1, 32, 0.0, dummy, None, None, None, None, None,
+                                       0, dummy, need, None) == -1
+    bargs = (dummy, dummy, dummy, 512, 1, 32, 0.0, None, dummy, None, dummy, dummy)
+    assert lib.lvae_encode_tail_bwd_ws_f32(*bargs, dummy, dummy, 0, dummy, need - 1, None) == -2
+    assert lib.lvae_encode_tail_bwd_ws_f32(*bargs, None, None, 0, dummy, need, None) == -1   # no output gradient
+    assert lib.lvae_encode_tail_bwd_ws_f32(*bargs, dummy, dummy, 1, dummy, need, None) == -4
+
+
 def test_no_cpu_fallback():
     """The product path must fail loudly instead of silently computing on the CPU."""
     from lvae import _native as N
