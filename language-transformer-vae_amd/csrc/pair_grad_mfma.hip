@@ -216,6 +216,152 @@ bwd_prep_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, 
         for (int idx = tid; idx < 32 * G; idx += 256) colgb_j[blk * 32 * G + idx] = sm_gb[(idx % G) * 32 + idx / G];
 }
 
+// ---- one 32x32 block of a sweep in the bf16-limb form, explicitly pipelined --------------------------------------------
+// Both contractions of a tile are chains of v_mfma_f32_32x32x16_bf16 whose operands come from LDS; left to the
+// compiler every chain starts with its LDS reads and a full wait for them, and the exponentials and the limb split sit
+// between the two contractions as one block of vector work: a wave then keeps the matrix pipe busy 40 % of its time
+// and three waves per SIMD reach 56-60 % (PMC).  Here the fragments (and, in sweep A, the row biases) of group g + 1
+// are read while the MFMAs of group g run, the sum over groups is folded one group late in the shadow of the next
+// chain, and the second half of the weights (exponentials + limb split of k-group 1) is formed behind the feature MFMAs
+// of k-group 0.  sched_barrier keeps the phases where they are put.
+template <int DP, bool ROWG>
+__device__ __forceinline__ void bwd_block_bx(const float* __restrict__ st, const float* __restrict__ tail, int lane, int h,
+                                             const bwd_bf16x8 (&bzx)[DP / 8][3], const float (&cg)[DP / 8], float cb,
+                                             f32x16 (&oacc)[DP / 16], float& wsum) {
+    constexpr int G = DP / 8, NFT = DP / 16;
+    constexpr int LA[6] = {1, 2, 0, 1, 0, 0};
+    constexpr int LB[6] = {1, 0, 2, 0, 1, 0};
+    const uint4* dr = reinterpret_cast<const uint4*>(st) + lane;
+    const uint4* fr = reinterpret_cast<const uint4*>(st + BWD_DENS_F(DP)) + lane;
+    auto load_d = [&](int g, bwd_bf16x8 (&d)[3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) d[l] = __builtin_bit_cast(bwd_bf16x8, dr[(g * 3 + l) * 64]);
+    };
+    auto init_acc = [&](int g, f32x16& a) __attribute__((always_inline)) {
+        if constexpr (ROWG) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) a[v] = cg[g];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(tail + g * 32 + 8 * q + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[4 * q + e] = b4[e];
+            }
+        }
+    };
+    auto load_f = [&](int idx, bwd_bf16x8 (&f)[3]) __attribute__((always_inline)) {      // idx = s * NFT + t
+        const int s2 = idx / NFT, t = idx % NFT;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) f[l] = __builtin_bit_cast(bwd_bf16x8, fr[((t * 2 + s2) * 3 + l) * 64]);
+    };
+    // ---- density: groups of eight dimensions, fragments and biases one group ahead ----
+    // (an explicit lgkmcnt(0) BEFORE each prefetch: the reads of the previous one have had a whole chain's issue time
+    //  to land, and the compiler then finds nothing pending when it reaches their first use -- left to itself it puts
+    //  its wait after the new reads and the wave sits out a full LDS round trip per group.  0xC07F = lgkmcnt(0) only.)
+    constexpr int NACC = ROWG ? 2 : 3;        // sweep A reads the next group's biases into a third accumulator image
+    bwd_bf16x8 da[2][3];
+    bwd_bf16x8 fa[2][3];
+    f32x16 acc[NACC];
+    f32x16 tot;
+    load_d(0, da[0]);
+    init_acc(0, acc[0]);
+    f32x4 n4[2];                              // row scalars of the exponent (and the row gradients in sweep B) of a k-group
+    f32x4 g4[ROWG ? 2 : 1];
+    auto load_rows = [&](int s2) __attribute__((always_inline)) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            n4[qq] = *reinterpret_cast<const f32x4*>(tail + G * 32 + 8 * (2 * s2 + qq) + 4 * h);
+            if constexpr (ROWG) g4[qq] = *reinterpret_cast<const f32x4*>(tail + (G + 1) * 32 + 8 * (2 * s2 + qq) + 4 * h);
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int cur = g % NACC, nxt = (g + 1) % NACC, prv = (g + NACC - 1) % NACC;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (g + 1 < G) {
+            load_d(g + 1, da[(g + 1) & 1]);
+            if constexpr (!ROWG) init_acc(g + 1, acc[nxt]);
+        } else {
+            load_rows(0);
+            load_f(0, fa[0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // (same (posterior limb, sample limb) order in both sweeps: see the comment in the kernel)
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr)
+            acc[cur] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[g & 1][ROWG ? LB[pr] : LA[pr]], bzx[g][ROWG ? LA[pr] : LB[pr]],
+                                                               acc[cur], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g >= 1) {                          // fold the previous group (its chain has had this one's issue time to finish)
+            if (g == 1) tot = acc[prv];
+            else tot += acc[prv];
+        }
+        if constexpr (ROWG)
+            if (g + 1 < G) init_acc(g + 1, acc[nxt]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (G == 1) tot = acc[0];
+    else tot += acc[(G - 1) % NACC];
+    // ---- weights of k-group 0, its limbs, then the feature MFMAs with the second half formed behind them ----
+    float w[16];
+    bwd_bf16x8 wl[2][3];
+    auto weights = [&](int s2) __attribute__((always_inline)) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int q = 2 * s2 + qq;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#ifdef BWD_DBG_NOEXP              // (ablation build: results are garbage)
+                float wv = tot[4 * q + e] + (n4[qq][e] + cb);
+#else
+                float wv = lvae_exp2(tot[4 * q + e] + (n4[qq][e] + cb));
+#endif
+                if constexpr (ROWG) wv *= g4[qq][e];
+                w[4 * q + e] = wv;
+                wsum += wv;
+            }
+        }
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            const f32x2 v = {w[8 * s2 + 2 * pr], w[8 * s2 + 2 * pr + 1]};
+            const bwd_bf16x2 hh = __builtin_convertvector(v, bwd_bf16x2);
+#ifdef BWD_DBG_NOSPLIT            // (ablation build: results are garbage)
+            const bwd_bf16x2 mm = hh, ll = hh;
+#else
+            const f32x2 r1 = v - __builtin_convertvector(hh, f32x2);
+            const bwd_bf16x2 mm = __builtin_convertvector(r1, bwd_bf16x2);
+            const f32x2 r2 = r1 - __builtin_convertvector(mm, f32x2);
+            const bwd_bf16x2 ll = __builtin_convertvector(r2, bwd_bf16x2);
+#endif
+            wl[s2][0][2 * pr] = hh[0];
+            wl[s2][0][2 * pr + 1] = hh[1];
+            wl[s2][1][2 * pr] = mm[0];
+            wl[s2][1][2 * pr + 1] = mm[1];
+            wl[s2][2][2 * pr] = ll[0];
+            wl[s2][2][2 * pr + 1] = ll[1];
+        }
+    };
+    weights(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int idx = 0; idx < 2 * NFT; ++idx) {
+        const int cur = idx & 1, s2 = idx / NFT, t = idx % NFT;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (idx + 1 < 2 * NFT) load_f(idx + 1, fa[cur ^ 1]);
+        if (idx == 0) load_rows(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr)
+            oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][LA[pr]], wl[s2][LB[pr]], oacc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (idx == 0) {                        // the other half of the weights, behind the MFMAs just issued
+            weights(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // ---- the sweep ---------------------------------------------------------------------------------------------------
 // partial [nsplit][cpad][2 DP]: per kept element the 2 DP feature sums; wsum [nsplit][cpad]: sum of its weights.  ROWG: weights carry the streamed row's gradient (sweep B); otherwise the kept element's own gradient is
 // applied by the merge kernel.
@@ -258,9 +404,11 @@ pair_bwd_mfma_kernel(const float* __restrict__ rec, const float* __restrict__ co
     const float cb = colbias[col];
     // ROWG: the kept posterior's group biases (the streamed samples have none) enter a chain as one more MFMA step,
     // ones x (bias in k-half 0, zero in k-half 1): no per-group accumulator images in registers, no vector adds
+    // (BX: the same bias as a broadcast into the sixteen accumulator registers of every lane -- bit-identical to the
+    //  ones x bias MFMA step and off the matrix pipe)
     float cg[DP / 8];
 #pragma unroll
-    for (int gi = 0; gi < DP / 8; ++gi) cg[gi] = (ROWG && h == 0) ? colgb[col * (DP / 8) + gi] : 0.f;
+    for (int gi = 0; gi < DP / 8; ++gi) cg[gi] = (ROWG && (BX || h == 0)) ? colgb[col * (DP / 8) + gi] : 0.f;
     f32x16 oacc[NFT];
 #pragma unroll
     for (int t = 0; t < NFT; ++t)
@@ -297,11 +445,17 @@ pair_bwd_mfma_kernel(const float* __restrict__ rec, const float* __restrict__ co
     for (int64_t blk = b0; blk < b1; ++blk) {
         const int stage = (int)((blk - b0) & 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef BWD_DBG_NOBAR             // (ablation build: results are garbage)
         __syncthreads();          // block `blk` is complete for everybody, and everybody is done with the other stage
+#endif
         if (blk + 1 < b1) dma_block(blk + 1, stage ^ 1);
         const float* st = ring + stage * REC;
         constexpr int G = DP / 8;
         const float* tail = st + BWD_TAIL_OFF(DP);
+        if constexpr (BX) {
+            bwd_block_bx<DP, ROWG>(st, tail, lane, h, bzx, cg, cb, oacc, wsum);
+            continue;
+        }
         f32x16 tot;
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
@@ -348,7 +502,11 @@ pair_bwd_mfma_kernel(const float* __restrict__ rec, const float* __restrict__ co
         for (int q = 0; q < 4; ++q) {
             const f32x4 n4 = *reinterpret_cast<const f32x4*>(tail + G * 32 + 8 * q + 4 * h);
 #pragma unroll
+#ifdef BWD_DBG_NOEXP              // (ablation build: results are garbage)
+            for (int e = 0; e < 4; ++e) w[4 * q + e] = tot[4 * q + e] + (n4[e] + cb);
+#else
             for (int e = 0; e < 4; ++e) w[4 * q + e] = lvae_exp2(tot[4 * q + e] + (n4[e] + cb));
+#endif
         }
         if constexpr (ROWG) {
 #pragma unroll
@@ -374,10 +532,14 @@ pair_bwd_mfma_kernel(const float* __restrict__ rec, const float* __restrict__ co
                 for (int pr = 0; pr < 4; ++pr) {
                     const f32x2 v = {w[8 * s2 + 2 * pr], w[8 * s2 + 2 * pr + 1]};
                     const bwd_bf16x2 hh = __builtin_convertvector(v, bwd_bf16x2);
+#ifdef BWD_DBG_NOSPLIT            // (ablation build: results are garbage)
+                    const bwd_bf16x2 mm = hh, ll = hh;
+#else
                     const f32x2 r1 = v - __builtin_convertvector(hh, f32x2);
                     const bwd_bf16x2 mm = __builtin_convertvector(r1, bwd_bf16x2);
                     const f32x2 r2 = r1 - __builtin_convertvector(mm, f32x2);
                     const bwd_bf16x2 ll = __builtin_convertvector(r2, bwd_bf16x2);
+#endif
                     wl[s2][0][2 * pr] = hh[0];
                     wl[s2][0][2 * pr + 1] = hh[1];
                     wl[s2][1][2 * pr] = mm[0];
