@@ -668,7 +668,8 @@ BwdMfmaLayout lvae_bwd_mfma_layout(int64_t M, int64_t N, int D) {
     L.cpad_i = lvae_round_up(M, 128);
     L.cpad_j = lvae_round_up(N, 128);
     // workgroups resident per CU: by LDS (two ring stages of a record) and registers
-    const int64_t slots = 256 * (L.DP <= 16 ? 4 : (L.DP <= 32 ? 3 : (L.DP <= 64 ? 2 : 1)));
+    // (D <= 16: 114-158 registers and 25 KB of ring; D <= 32: 192-244 registers, the pipelined bf16-limb body)
+    const int64_t slots = 256 * (L.DP <= 16 ? 3 : (L.DP <= 64 ? 2 : 1));
     auto split = [&](int64_t kept_pad, int64_t rows, int* ns, int64_t* bps) {
         const int64_t groups = kept_pad / 128, nblk = lvae_ceil_div(rows, 32);
         int64_t c = (2 * slots + groups / 2) / groups;
