@@ -21,6 +21,7 @@
 #define MID_THREADS 256
 #define MID_MAX_D 64
 #define MID_MAX_B 4096
+#define MID_EPT (MID_JC * MID_MAX_D / MID_THREADS)      // elements of a chunk array per thread, at most
 
 struct MidGeom {
     int B, K, D;
@@ -116,23 +117,46 @@ encode_tail_mid_kernel(const float* __restrict__ mu, const float* __restrict__ l
     const bool d_ok = dd < D;
     const float inv = 1.0f / ((float)D * (float)D);
     (void)irow;
+    // the chunk after the one being consumed is already on its way into registers (MID_EPT elements per thread and
+    // array): a chunk's global loads would otherwise be a latency of their own between two barriers, for every chunk
+    float pf_m[MID_EPT], pf_lv[MID_EPT], pf_e[MID_EPT], pf_x[MID_EPT];
+    auto fetch = [&](int j0) __attribute__((always_inline)) {
+        const int jn = B - j0 < MID_JC ? B - j0 : MID_JC;
+#pragma unroll
+        for (int u = 0; u < MID_EPT; ++u) {
+            const int e = tid + u * MID_THREADS;
+            if (e < jn * D) {
+                const int r = e / D, d = e - r * D;
+                const int64_t j = j0 + r;
+                pf_m[u] = mu[j * D + d];
+                pf_lv[u] = logvar[j * D + d];
+                pf_e[u] = eps[j * K * D + d];
+                pf_x[u] = prior ? prior[j * D + d] : 0.f;
+            }
+        }
+    };
+    fetch(0);
     for (int j0 = 0; j0 < B; j0 += MID_JC) {
         __syncthreads();                    // the previous chunk is consumed (first trip: the tile rows are written)
         const int jn = B - j0 < MID_JC ? B - j0 : MID_JC;
-        for (int e = tid; e < jn * D; e += MID_THREADS) {
-            const int r = e / D, d = e - r * D;
-            const int64_t j = j0 + r;
-            const float m = mu[j * D + d], lv = logvar[j * D + d];
-            s_mu[r * DS + d] = m;
-            s_lv[r * DS + d] = lv;
-            s_iv[r * DS + d] = expf(-lv);
-            s_z0[r * DS + d] = mid_z(m, lv, eps[j * K * D + d]);
-            s_x[r * DS + d] = prior ? prior[j * D + d] : 0.f;
+#pragma unroll
+        for (int u = 0; u < MID_EPT; ++u) {
+            const int e = tid + u * MID_THREADS;
+            if (e < jn * D) {
+                const int r = e / D, d = e - r * D;
+                s_mu[r * DS + d] = pf_m[u];
+                s_lv[r * DS + d] = pf_lv[u];
+                s_iv[r * DS + d] = expf(-pf_lv[u]);
+                s_z0[r * DS + d] = mid_z(pf_m[u], pf_lv[u], pf_e[u]);
+                s_x[r * DS + d] = pf_x[u];
+            }
         }
         __syncthreads();
+        if (j0 + MID_JC < B) fetch(j0 + MID_JC);
         if (lane < jn) {
             float acc = 0.f, dxx = 0.f, dyy = 0.f, dxy = 0.f;
             if (prior) {
+#pragma unroll 4
                 for (int d = 0; d < D; ++d) {
                     const float zv = t_z0[wave * DS + d], xv = t_x[wave * DS + d];
                     acc += MID_TERM(zv, lane, d);
@@ -145,12 +169,14 @@ encode_tail_mid_kernel(const float* __restrict__ mu, const float* __restrict__ l
                 a_yy += (double)__expf(-dyy * inv);
                 a_xy += (double)__expf(-dxy * inv);
             } else {
-                for (int d = 0; d < D; ++d) acc += MID_TERM(t_z0[wave * DS + d], lane, d);
+#pragma unroll 4
+            for (int d = 0; d < D; ++d) acc += MID_TERM(t_z0[wave * DS + d], lane, d);
             }
             mid_push(jm, js, acc);
         }
         if (d_ok) {
             const float zv = t_z0[wave * DS + dd];
+#pragma unroll 4
             for (int r = jq; r < jn; r += G.JQ) mid_push(pmx, psum, MID_TERM(zv, r, dd));
         }
     }
@@ -243,16 +269,35 @@ encode_tail_mid_bwd_a_kernel(const float* __restrict__ mu, const float* __restri
     }
     const int dd = lane % G.DPAD, jq = lane / G.DPAD;
     const bool d_ok = dd < D;
-    auto load_chunk = [&](int j0, int jn) {
-        for (int e = tid; e < jn * D; e += MID_THREADS) {
-            const int r = e / D, d = e - r * D;
-            const int64_t j = j0 + r;
-            const float lv = logvar[j * D + d];
-            s_mu[r * DS + d] = mu[j * D + d];
-            s_lv[r * DS + d] = lv;
-            s_iv[r * DS + d] = expf(-lv);
+    // (the next chunk travels into registers while the current one is consumed, as in the forward kernel; the two
+    //  passes form one sequence of 2 * ceil(B / 64) chunks)
+    float pf_m[MID_EPT], pf_lv[MID_EPT];
+    auto fetch = [&](int j0) __attribute__((always_inline)) {
+        const int jn = B - j0 < MID_JC ? B - j0 : MID_JC;
+#pragma unroll
+        for (int u = 0; u < MID_EPT; ++u) {
+            const int e = tid + u * MID_THREADS;
+            if (e < jn * D) {
+                const int r = e / D, d = e - r * D;
+                pf_m[u] = mu[(int64_t)(j0 + r) * D + d];
+                pf_lv[u] = logvar[(int64_t)(j0 + r) * D + d];
+            }
         }
     };
+    auto load_chunk = [&](int j0, int jn) __attribute__((always_inline)) {
+        (void)j0;
+#pragma unroll
+        for (int u = 0; u < MID_EPT; ++u) {
+            const int e = tid + u * MID_THREADS;
+            if (e < jn * D) {
+                const int r = e / D, d = e - r * D;
+                s_mu[r * DS + d] = pf_m[u];
+                s_lv[r * DS + d] = pf_lv[u];
+                s_iv[r * DS + d] = expf(-pf_lv[u]);
+            }
+        }
+    };
+    fetch(0);
     // pass 1: the two kinds of logsumexp
     float jm = -INFINITY, js = 0.f, pmx = -INFINITY, psum = 0.f;
     for (int j0 = 0; j0 < B; j0 += MID_JC) {
@@ -260,13 +305,16 @@ encode_tail_mid_bwd_a_kernel(const float* __restrict__ mu, const float* __restri
         const int jn = B - j0 < MID_JC ? B - j0 : MID_JC;
         load_chunk(j0, jn);
         __syncthreads();
+        fetch(j0 + MID_JC < B ? j0 + MID_JC : 0);          // (after the last chunk: the first one again, for pass 2)
         if (lane < jn) {
             float acc = 0.f;
+#pragma unroll 4
             for (int d = 0; d < D; ++d) acc += MID_TERM(t_z0[wave * DS + d], lane, d);
             mid_push(jm, js, acc);
         }
         if (d_ok) {
             const float zv = t_z0[wave * DS + dd];
+#pragma unroll 4
             for (int r = jq; r < jn; r += G.JQ) mid_push(pmx, psum, MID_TERM(zv, r, dd));
         }
     }
@@ -286,8 +334,10 @@ encode_tail_mid_bwd_a_kernel(const float* __restrict__ mu, const float* __restri
         const int jn = B - j0 < MID_JC ? B - j0 : MID_JC;
         load_chunk(j0, jn);
         __syncthreads();
+        if (j0 + MID_JC < B) fetch(j0 + MID_JC);
         if (lane < jn) {
             float v = 0.f;
+#pragma unroll 4
             for (int d = 0; d < D; ++d) v += MID_TERM(t_z0[wave * DS + d], lane, d);
             const float P = wq * expf(v - lq);
             t_P[wave * MID_JC + lane] = P;
@@ -295,6 +345,7 @@ encode_tail_mid_bwd_a_kernel(const float* __restrict__ mu, const float* __restri
         }
         __syncthreads();
         if (d_ok) {
+#pragma unroll 4
             for (int r = jq; r < jn; r += G.JQ) {
                 const float df = zv - s_mu[r * DS + dd];
                 const float a = df * s_iv[r * DS + dd];
@@ -339,20 +390,40 @@ encode_tail_mid_bwd_b_kernel(const float* __restrict__ mu, const float* __restri
     const float iv = expf(-lv), base = lv + LVAE_LOG_2PI;
     float am = 0.f, av = 0.f;
     if (pair_terms) {
+        float pf_z[MID_EPT], pf_l[MID_EPT], pf_p = 0.f;
+        auto fetch = [&](int i0) __attribute__((always_inline)) {
+            const int in = B - i0 < MID_JC ? B - i0 : MID_JC;
+#pragma unroll
+            for (int u = 0; u < MID_EPT; ++u) {
+                const int e = tid + u * MID_THREADS;
+                if (e < in * D) {       // (z0 and lse are [B, D] row-major: a chunk is one contiguous run)
+                    pf_z[u] = z0_ws[(int64_t)i0 * D + e];
+                    pf_l[u] = lse_ws[(int64_t)i0 * D + e];
+                }
+            }
+            if (tid < in * MID_TI) {
+                const int r = tid / MID_TI, w = tid - r * MID_TI;
+                pf_p = j0t + w < B ? P_ws[(int64_t)(i0 + r) * B + j0t + w] : 0.f;
+            }
+        };
+        fetch(0);
         for (int i0 = 0; i0 < B; i0 += MID_JC) {
             __syncthreads();
             const int in = B - i0 < MID_JC ? B - i0 : MID_JC;
-            for (int e = tid; e < in * D; e += MID_THREADS) {
-                const int r = e / D, d = e - r * D;
-                c_z0[r * DS + d] = z0_ws[(int64_t)(i0 + r) * D + d];
-                c_lse[r * DS + d] = lse_ws[(int64_t)(i0 + r) * D + d];
+#pragma unroll
+            for (int u = 0; u < MID_EPT; ++u) {
+                const int e = tid + u * MID_THREADS;
+                if (e < in * D) {
+                    const int r = e / D, d = e - r * D;
+                    c_z0[r * DS + d] = pf_z[u];
+                    c_lse[r * DS + d] = pf_l[u];
+                }
             }
-            for (int e = tid; e < in * MID_TI; e += MID_THREADS) {
-                const int r = e / MID_TI, w = e - r * MID_TI;
-                c_P[e] = j0t + w < B ? P_ws[(int64_t)(i0 + r) * B + j0t + w] : 0.f;
-            }
+            if (tid < in * MID_TI) c_P[tid] = pf_p;
             __syncthreads();
+            if (i0 + MID_JC < B) fetch(i0 + MID_JC);
             if (d_ok) {
+#pragma unroll 4
                 for (int r = iq; r < in; r += G.JQ) {
                     const float df = c_z0[r * DS + dd] - m;
                     const float a = df * iv;
