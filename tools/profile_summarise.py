@@ -50,6 +50,11 @@ traffic = {
 }
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 
+# matrix-core backward: counters per launch of the two sweeps
+if os.path.isdir(os.path.join(src, "pmc_bwd_a")) and os.path.isdir(os.path.join(src, "pmc_bwd_b")):
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(dst, "pmc_bwd.json"),
+                           os.path.join(src, "pmc_bwd_a"), os.path.join(src, "pmc_bwd_b")], stdout=subprocess.DEVNULL)
+
 # split-bf16 pair kernel: MFMA utilisation by cycles and the clock it ran at
 kt, cc = first("pmc_bf16x3/**/*kernel_trace.csv"), first("pmc_bf16x3/**/*counter_collection.csv")
 if kt and cc:
