@@ -32,13 +32,16 @@
 
 // floats of one 32-row record: density operand | features | tail = group biases [DP/8][32], normaliser [32], g [32]
 // (the tail padded to whole 64-float DMA pieces)
-// BX (D <= 32): the features are stored as three bf16 limbs each, in the fragment order of v_mfma_f32_32x32x16_bf16
+// BX (D <= 64): the features are stored as three bf16 limbs each, in the fragment order of v_mfma_f32_32x32x16_bf16
 // (see the sweep kernel): (DP / 16) feature tiles x 2 k-groups x 3 limbs pieces of 1 KiB.
 #define BWD_TAIL_PIECES(DP) (((DP) / 8 + 2 + 1) / 2)
 #ifdef BWD_FORCE_FP32
 #define BWD_BX(DP) (false && (DP) > 0)
 #else
-#define BWD_BX(DP) ((DP) <= 32)
+#ifndef BWD_BX_MAX
+#define BWD_BX_MAX 64          // widest padded D on the bf16-limb form (D = 128: two ring stages would need 196 KB of LDS)
+#endif
+#define BWD_BX(DP) ((DP) <= BWD_BX_MAX)
 #endif
 #define BWD_FEAT_F(DP) (BWD_BX(DP) ? ((DP) / 16) * 6 * 256 : 64 * (DP))
 // ... and so is the density operand: (DP / 8) steps of eight dimensions x 3 limbs pieces of 1 KiB for a streamed block,
@@ -668,8 +671,10 @@ BwdMfmaLayout lvae_bwd_mfma_layout(int64_t M, int64_t N, int D) {
     L.cpad_i = lvae_round_up(M, 128);
     L.cpad_j = lvae_round_up(N, 128);
     // workgroups resident per CU: by LDS (two ring stages of a record) and registers
-    // (D <= 16: 114-158 registers and 25 KB of ring; D <= 32: 192-244 registers, the pipelined bf16-limb body)
-    const int64_t slots = 256 * (L.DP <= 16 ? 3 : (L.DP <= 64 ? 2 : 1));
+    // (D <= 16: 122-166 registers and 25 KB of ring; D <= 32: 192-256 registers, the pipelined bf16-limb body;
+    //  D <= 64 in that form: 330-448 registers and 99 KB of ring, one workgroup = one wave per SIMD -- the explicit
+    //  pipelining is what keeps the matrix pipe fed there: 16,384^2 2.36 -> 1.75 ms against the fp32 contractions at two)
+    const int64_t slots = 256 * (L.DP <= 16 ? 3 : (L.DP <= 32 || (L.DP == 64 && !BWD_BX(64)) ? 2 : 1));
     auto split = [&](int64_t kept_pad, int64_t rows, int* ns, int64_t* bps) {
         const int64_t groups = kept_pad / 128, nblk = lvae_ceil_div(rows, 32);
         int64_t c = (2 * slots + groups / 2) / groups;
@@ -738,7 +743,7 @@ int lvae_launch_bwd_mfma(const BwdMfmaLayout& L, void* ws, const float* z, const
     switch (L.DP) {
         case 16: launch_sweeps<16, 2>(L, base, M, N, g, want_p, hdr, cond_limit, st); break;
         case 32: launch_sweeps<32, 2>(L, base, M, N, g, want_p, hdr, cond_limit, st); break;
-        case 64: launch_sweeps<64, 2>(L, base, M, N, g, want_p, hdr, cond_limit, st); break;
+        case 64: launch_sweeps<64, BWD_BX(64) ? 1 : 2>(L, base, M, N, g, want_p, hdr, cond_limit, st); break;
         default: launch_sweeps<128, 1>(L, base, M, N, g, want_p, hdr, cond_limit, st); break;
     }
     if (want_z)
