@@ -34,7 +34,7 @@ timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
 step "PMC SQ + clock of the split-bf16 pair kernel"
 timeout -s KILL 150 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_bf16x3" -o p -- python3 $R/tools/run_path.py 3 65536 32 20 > "$OUT/pmc_bf16x3.log" 2>&1 || exit 1
 step "kernel trace of the matrix-core backward"
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_bwd" -o p -- python3 $R/tools/bench_bwd.py 16384,16384,32 16384,16384,64 16384,16384,128 65536,65536,32 > "$OUT/bwd.log" 2>&1 || exit 1
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_bwd" -o p -- python3 $R/tools/bench_bwd.py 16384,16384,32 16384,16384,64 16384,16384,128 65536,65536,32 65536,65536,64 42068,42068,64 8192,8192,64 > "$OUT/bwd.log" 2>&1 || exit 1
 step "PMC of the matrix-core backward (two passes)"
 LVAE_BWD_PATH=mfma timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_MFMA SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_bwd_a" -o p -- python3 $R/tools/bench_bwd.py 16384,16384,32 > "$OUT/pmc_bwd_a.log" 2>&1 || exit 1
 LVAE_BWD_PATH=mfma timeout -s KILL 120 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT/pmc_bwd_b" -o p -- python3 $R/tools/bench_bwd.py 16384,16384,32 > "$OUT/pmc_bwd_b.log" 2>&1 || exit 1
