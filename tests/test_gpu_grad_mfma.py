@@ -49,17 +49,17 @@ def _problem(seed, M, N, D, sigma_scale=1.0):
 
 
 @pytest.mark.parametrize("M,N,D", [(2048, 3000, 32), (1500, 2500, 8), (3000, 2048, 48), (2100, 2000, 100),
-                                   (2048, 2048, 128), (130, 70, 32)])
+                                   (2048, 2048, 128), (130, 70, 32), (4100, 5000, 64), (9000, 600, 33)])
 def test_matrix_core_backward_vs_float64_autograd(M, N, D, lvae_env):
     lvae_env.set("LVAE_BWD_PATH", "mfma")
     mu, lv, z, a = _problem(M + D, M, N, D)
     _check(_our_grads(mu, lv, z, a), _reference_grads(mu, lv, z, a, math.log(N)))
 
 
-@pytest.mark.parametrize("D,tol", [(31, 1e-4), (16, 1e-4), (64, 3e-4)])      # (D = 64: fp32 contractions; a far sample's
-def test_far_samples_keep_normalised_weights(D, tol, lvae_env):               #  |v| ~ 2e4 costs d_z one ulp of it: 1.2e-4)
+@pytest.mark.parametrize("D,tol", [(31, 1e-4), (16, 1e-4), (64, 3e-4)])   # (the wider the latent, the farther the
+def test_far_samples_keep_normalised_weights(D, tol, lvae_env):                        #  far samples: |v| ~ 2e4 at D = 64 costs d_z one ulp of it, 1.2e-4)
     """Samples far from every posterior (|v| ~ 1e4): their weights only come out right because sweep B evaluates v_ij
-    bit-identically to sweep A, whose sums normalise them -- with the bf16-limb contraction (D <= 32) that needs the limb
+    bit-identically to sweep A, whose sums normalise them -- with the bf16-limb contraction (D <= 64) that needs the limb
     products accumulated in the same order in both sweeps (4e-4 on d_mu otherwise, 1e-6 with it)."""
     lvae_env.set("LVAE_BWD_PATH", "mfma")
     M, N = 1546, 653
