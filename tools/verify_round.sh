@@ -10,6 +10,8 @@ timeout -k 10 300 python -u tests/fuzz_bwd.py 500 200 > gpurun_out/r3v/fuzz_bwd.
 tail -2 gpurun_out/r3v/fuzz_bwd.log
 timeout -k 10 300 python -u tests/fuzz_iw.py 400 5 > gpurun_out/r3v/fuzz_iw.log 2>&1 || { tail -20 gpurun_out/r3v/fuzz_iw.log; exit 1; }
 tail -1 gpurun_out/r3v/fuzz_iw.log
+timeout -k 10 300 python -u tests/fuzz_tail.py 150 3 > gpurun_out/r3v/fuzz_tail.log 2>&1 || { tail -20 gpurun_out/r3v/fuzz_tail.log; exit 1; }
+tail -1 gpurun_out/r3v/fuzz_tail.log
 LVAE_BENCH_REHEARSAL=1 timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1 > gpurun_out/r3v/bench_torchrun2.log 2>&1 || { tail -20 gpurun_out/r3v/bench_torchrun2.log; exit 1; }
 grep '^{"metric"' gpurun_out/r3v/bench_torchrun2.log | cut -c1-300
 timeout -k 10 300 python bench.py > gpurun_out/r3v/bench.log 2>&1 || { tail -20 gpurun_out/r3v/bench.log; exit 1; }
