@@ -12,6 +12,7 @@
 // for latent sizes the MFMA path does not cover.  Bound: VALU / transcendental rate (one v_exp_f32
 // per (i,j,d) term with PM), not HBM.
 #include "pair_plan.h"
+#include <cstdlib>
 
 #define DLSE_THR 8.0f
 #define DLSE_MINIT (-1.0e30f)
@@ -195,6 +196,97 @@ pair_pm_online_kernel(const float* __restrict__ z, const float* __restrict__ dpa
     }
 }
 
+// Latent rows too wide for registers (DC > 64; D = 768 is the reference's module default, modules/encoder.py:9): the
+// sweep is blocked JB posteriors x 16 dimensions.  A lane keeps JB partial sums v_ij (one per posterior of the batch)
+// and walks the latent row in chunks of sixteen dimensions: its own sixteen z values come from global memory once per
+// (batch, chunk) -- 64 B contiguous per lane, re-used for all JB posteriors --, the posteriors' parameters through
+// wave-uniform (scalar) loads, three vector instructions per (i, j, d).  The per-dimension biases do not depend on the
+// sample: lane l sums them for posterior l of the batch and the sums are broadcast once per batch.  Exact differences
+// like the other direct kernels.  (The one-row-at-a-time generic kernel below re-read z_id from global memory, one
+// 4-byte element per lane and 64 cache lines per wave-load, for every (j, d): 377 ms at 16,384^2, D = 768.)
+template <int JB>
+__global__ void __launch_bounds__(256)
+pair_direct_wide_kernel(const float* __restrict__ z, const float* __restrict__ dparams,
+                        float2* __restrict__ partial, const PairHeader* __restrict__ hdr,
+                        float cond_limit, int use_if_above, int64_t C, int64_t cpad, int64_t R,
+                        int64_t rows_per_split, int D, int DC, int excl, int64_t excl_offset) {
+    if (cond_limit >= 0.f) {
+        const float cond = __uint_as_float(hdr->cond_bits);
+        if ((cond > cond_limit) != (use_if_above != 0)) return;
+    }
+    static_assert(JB <= 64, "one lane per posterior of a batch sums its biases");
+    const int lane = threadIdx.x & 63;
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = col < C ? col : C - 1;
+    const float* __restrict__ zi = z + i * D;
+    const bool vec4 = (D & 3) == 0;          // 16-byte loads of the row (rows are then 16-byte aligned)
+    float mv = DLSE_MINIT, sv = 0.f;
+    const int64_t j0 = (int64_t)blockIdx.y * rows_per_split;
+    int64_t j1 = j0 + rows_per_split;
+    if (j1 > R) j1 = R;
+    const int64_t jskip = excl ? i + excl_offset : -1;
+    for (int64_t jb = j0; jb < j1; jb += JB) {
+        // bias sums of the batch: lane l owns posterior jb + l
+        float bsum = 0.f;
+        if (lane < JB && jb + lane < j1) {
+            const float* __restrict__ pb = dparams + ((jb + lane) * 3 + 2) * DC;
+            float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+            for (int d = 0; d < DC; d += 4) {
+                const float4 q = *reinterpret_cast<const float4*>(pb + d);
+                b0 += q.x; b1 += q.y; b2 += q.z; b3 += q.w;
+            }
+            bsum = (b0 + b1) + (b2 + b3);
+        }
+        float v[JB];
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) v[jj] = 0.f;
+        for (int d0 = 0; d0 < DC; d0 += 16) {
+            float zr[16];
+            if (vec4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int d = d0 + 4 * q;
+                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (d < D) t = *reinterpret_cast<const float4*>(zi + d);
+                    zr[4 * q] = t.x; zr[4 * q + 1] = t.y; zr[4 * q + 2] = t.z; zr[4 * q + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) zr[e] = d0 + e < D ? zi[d0 + e] : 0.f;
+            }
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj) {
+                // (a batch past the end of the split repeats its last posterior: its sums are dropped below)
+                const int64_t j = jb + jj < j1 ? jb + jj : j1 - 1;
+                const float* __restrict__ pm = dparams + (j * 3 + 0) * DC + d0;
+                const float* __restrict__ pw = dparams + (j * 3 + 1) * DC + d0;
+                float a = v[jj];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float y = (zr[e] - pm[e]) * pw[e];
+                    a = fmaf(-y, y, a);
+                }
+                v[jj] = a;
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) {
+            if (jb + jj < j1) {                                  // (wave-uniform)
+                float vv = v[jj] + __shfl(bsum, jj, 64);
+                if (jb + jj == jskip) vv = -INFINITY;
+                const float xv = vv - mv;
+                if (xv > DLSE_THR) {
+                    sv = sv * lvae_exp2(-xv) + 1.0f;
+                    mv = vv;
+                } else {
+                    sv += lvae_exp2(xv);
+                }
+            }
+        }
+    }
+    if (col < C) partial[(int64_t)blockIdx.y * cpad + col] = make_float2(mv, sv);
+}
+
 // Any latent size: the sample row is re-read from global memory (L1/L2 resident) for every posterior.
 __global__ void __launch_bounds__(256)
 pair_direct_generic_kernel(const float* __restrict__ z, const float* __restrict__ dparams,
@@ -278,9 +370,16 @@ int lvae_launch_pair_direct(const PairPlan& p, bool joint, bool pm, const float*
         else if (DC == 64) rc = launch_joint<64>(p, z, dparams, partial, hdr, cond_limit, use_if_above, excl, excl_offset, st);
         else {
             const dim3 grid((unsigned)(p.cpad / 256), (unsigned)p.dsplit);
-            hipLaunchKernelGGL(pair_direct_generic_kernel, grid, dim3(256), 0, st, z, dparams, partial,
-                               hdr, cond_limit, use_if_above, p.C, p.cpad, p.R, p.rows_per_dsplit, p.D,
-                               DC, excl, excl_offset);
+            // (LVAE_DIRECT_GENERIC=1, read once per process: the one-row-at-a-time kernel, for comparisons)
+            static const bool force_generic = getenv("LVAE_DIRECT_GENERIC") != nullptr;
+            if (DC % 16 == 0 && !force_generic)
+                hipLaunchKernelGGL((pair_direct_wide_kernel<32>), grid, dim3(256), 0, st, z, dparams, partial,
+                                   hdr, cond_limit, use_if_above, p.C, p.cpad, p.R, p.rows_per_dsplit, p.D,
+                                   DC, excl, excl_offset);
+            else
+                hipLaunchKernelGGL(pair_direct_generic_kernel, grid, dim3(256), 0, st, z, dparams, partial,
+                                   hdr, cond_limit, use_if_above, p.C, p.cpad, p.R, p.rows_per_dsplit, p.D,
+                                   DC, excl, excl_offset);
             LVAE_LAUNCH_CHECK();
         }
         if (rc != LVAE_OK) return rc;

@@ -50,7 +50,10 @@ def test_log_qz_golden(case, path):
 
 
 @pytest.mark.parametrize("N,M,D", [(1000, 777, 32), (4096, 4096, 32), (513, 2049, 64), (300, 300, 128),
-                                    (200, 100, 8), (150, 90, 48), (64, 64, 200)])
+                                    (200, 100, 8), (150, 90, 48), (64, 64, 200),
+                                    # wide latents (the blocked direct kernel: batches of 32 posteriors x 16 dimensions;
+                                    # D % 4 != 0 takes its scalar row loads, N % 32 != 0 a ragged last batch)
+                                    (300, 257, 768), (97, 300, 201), (33, 513, 130), (1100, 70, 256)])
 def test_log_qz_vs_oracle(N, M, D):
     from lvae import estimators as E
     rng = np.random.default_rng(N + M + D)

@@ -60,9 +60,10 @@ def test_mi_bounds(case):
     assert lower <= np.log(len(g["z"])) + 1e-5      # InfoNCE <= log K (float32 rounding slack)
 
 
-@pytest.mark.parametrize("K,D", [(1500, 32), (700, 16), (900, 64), (600, 100), (500, 128)])
+@pytest.mark.parametrize("K,D", [(1500, 32), (700, 16), (900, 64), (600, 100), (500, 128), (333, 768), (290, 201)])
 def test_mi_bounds_large_vs_oracle(K, D):
-    """(every width of the pair kernel with the diagonal excluded: D = 16 / 32 / 64 / 128 variants)"""
+    """(every width of the pair kernel with the diagonal excluded: D = 16 / 32 / 64 / 128 variants, and the blocked
+    direct kernel of wider latents -- 768 is the reference's module default, modules/encoder.py:9)"""
     from lvae import mutual_information as MI
     rng = np.random.default_rng(3)
     mu = rng.standard_normal((K, D)).astype(np.float32)
