@@ -215,13 +215,16 @@ static inline PairPlan lvae_make_pair_plan(int64_t R, int64_t C, int D, bool wit
     // six of them resident per CU (1536 on the chip).  Measured with the prod-marginals kernel: three rounds
     // of workgroups beat one by 9 % on large problems, while on small ones every extra split costs more in
     // partials (dsplit x cpad x DC x 8 B, written and merged) than it gains: aim at 4608 / 1536 / 768
-    // workgroups by size, never fewer than 128 reduced rows per split.
+    // workgroups by size, never fewer than 128 reduced rows per split (32 for latent rows wider than 64).
     {
         const int64_t dgroups = p.cpad / 256 > 0 ? p.cpad / 256 : 1;
         const int64_t target = dgroups >= 192 ? 4608 : (dgroups >= 96 ? 1536 : 768);
         int64_t ds = lvae_ceil_div(target, dgroups);
         if (lvae_switches().dsplit) ds = lvae_switches().dsplit;
-        if (ds > R / 128) ds = R / 128;
+        // (wide latent rows carry D / 32 times the work per pair: a training batch of 256 at D = 768 is worth
+        //  eight workgroups, not two)
+        const int64_t min_rows = D > 64 ? 32 : 128;
+        if (ds > R / min_rows) ds = R / min_rows;
         if (ds > 64) ds = 64;
         if (ds < 1) ds = 1;
         p.rows_per_dsplit = lvae_round_up(lvae_ceil_div(R, ds), 32);    // whole 32-row blocks (the bf16 prod-marginals

@@ -343,6 +343,107 @@ sample_iw_generic_kernel(const float* __restrict__ mu, const float* __restrict__
     }
 }
 
+// Latent sizes the vector kernel does not take (D / 4 not a power of two up to 64: 20, 48, 100, 768 ...), up to
+// D = 1024: a WAVE per sample row, lanes along the row (coalesced 16-byte loads when D % 4 == 0), the sentence's
+// posterior constants in registers, one wave reduction per row; the four waves of a workgroup share a sentence.
+// (The one-lane-per-row kernel above walks each row with 4-byte loads a row apart in every lane and evaluates two
+//  exponentials and a division per element: 0.57 TB/s at D = 768.)
+template <bool FROM_EPS, bool VEC>
+__global__ void __launch_bounds__(256)
+sample_iw_waverow_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                         const float* __restrict__ src, const float* __restrict__ log_p_x_z, int64_t K,
+                         int D, float* __restrict__ z_out, float* __restrict__ log_q_z_x,
+                         float* __restrict__ log_p_z, float* __restrict__ iw_ll) {
+    constexpr int W = VEC ? 4 : 1;              // elements per lane and step
+    constexpr int MAXS = VEC ? 4 : 16;          // steps of 64 lanes: D <= 1024
+    const int64_t b = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool have_post = mu != nullptr;
+    float m[MAXS][W], sd[MAXS][W], var[MAXS][W];
+    float cq = 0.f, cp = 0.f;                   // this lane's share of the constants of log q(z|x) and log p(z)
+#pragma unroll
+    for (int st = 0; st < MAXS; ++st)
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            const int d = (st * 64 + lane) * W + e;
+            m[st][e] = 0.f;
+            sd[st][e] = 1.f;
+            var[st][e] = 1.f;
+            if (d < D) {
+                cp += -0.5f * LVAE_LOG_2PI;
+                if (have_post) {
+                    const float lv = logvar[b * D + d];
+                    m[st][e] = mu[b * D + d];
+                    sd[st][e] = expf(0.5f * lv);
+                    var[st][e] = expf(lv);
+                    cq += -0.5f * (lv + LVAE_LOG_2PI);
+                }
+            }
+        }
+    float lm = -INFINITY, ls = 0.f;
+    for (int64_t k = wave; k < K; k += 4) {
+        const float* __restrict__ row = src + (b * K + k) * D;
+        float* __restrict__ zrow = (FROM_EPS && z_out) ? z_out + (b * K + k) * D : nullptr;
+        float q = 0.f, p = 0.f;
+#pragma unroll
+        for (int st = 0; st < MAXS; ++st) {
+            const int d0 = (st * 64 + lane) * W;
+            if (d0 < D) {
+                float v[W], zz[W];
+                if (VEC) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(row + d0);
+#pragma unroll
+                    for (int e = 0; e < W; ++e) v[e] = t[e];
+                } else {
+                    v[0] = row[d0];
+                }
+#pragma unroll
+                for (int e = 0; e < W; ++e) {
+                    zz[e] = (FROM_EPS && have_post) ? __fadd_rn(m[st][e], __fmul_rn(v[e], sd[st][e])) : v[e];
+                    if (have_post) {
+                        const float df = zz[e] - m[st][e];
+                        q += __fdiv_rn(df * df, var[st][e]);
+                    }
+                    p = fmaf(zz[e], zz[e], p);
+                }
+                if (zrow) {
+                    if (VEC) {
+                        f32x4 t;
+#pragma unroll
+                        for (int e = 0; e < W; ++e) t[e] = zz[e];
+                        *reinterpret_cast<f32x4*>(zrow + d0) = t;
+                    } else {
+                        zrow[d0] = zz[0];
+                    }
+                }
+            }
+        }
+        const float lq = have_post ? wave_sum(cq - 0.5f * q) : 0.f;
+        const float lp = wave_sum(cp - 0.5f * p);
+        if (lane == 0) {
+            if (log_q_z_x) log_q_z_x[b * K + k] = lq;
+            if (log_p_z) log_p_z[b * K + k] = lp;
+        }
+        if (iw_ll) lse_push(lm, ls, (log_p_x_z ? log_p_x_z[b * K + k] : 0.f) + lp - lq);
+    }
+    if (iw_ll) {
+        __shared__ float sm_m[4], sm_s[4];
+        if (lane == 0) {
+            sm_m[wave] = lm;
+            sm_s[wave] = ls;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float mx = -INFINITY;
+            for (int t = 0; t < 4; ++t) mx = fmaxf(mx, sm_m[t]);
+            double s2 = 0.0;
+            for (int t = 0; t < 4; ++t)
+                if (sm_s[t] > 0.f) s2 += (double)sm_s[t] * exp((double)sm_m[t] - (double)mx);
+            iw_ll[b] = (float)((double)mx + log(s2) - log((double)K));
+        }
+    }
+}
+
 // Element-wise (no latent reduction): sample_log_likelihood(..., reduce_latent_dim=False).
 __global__ void __launch_bounds__(256)
 sample_ll_elem_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
@@ -499,6 +600,15 @@ int lvae_launch_sample_iw(bool from_eps, const float* mu, const float* logvar, c
 #undef LVAE_SIW3
 #undef LVAE_SIW2
 #undef LVAE_SIW
+    } else if (D <= 1024 && !lvae_switches().iw_no_stage) {
+        // (D % 4 == 0 makes every row 16-byte aligned: the tensors are whole allocations or 16-byte aligned views)
+        const bool vec = D % 4 == 0 && (((uintptr_t)src | (uintptr_t)z_out) & 15) == 0;
+#define LVAE_SIWR(E, V)                                                                                              \
+    hipLaunchKernelGGL((sample_iw_waverow_kernel<E, V>), grid, dim3(256), 0, st, mu, logvar, src, log_p_x_z, K, D, z_out, \
+                       log_q_z_x, log_p_z, iw_ll)
+        if (from_eps) { if (vec) LVAE_SIWR(true, true); else LVAE_SIWR(true, false); }
+        else { if (vec) LVAE_SIWR(false, true); else LVAE_SIWR(false, false); }
+#undef LVAE_SIWR
     } else {
         if (from_eps)
             hipLaunchKernelGGL(sample_iw_generic_kernel<true>, grid, dim3(256), 0, st, mu, logvar, src,

@@ -17,7 +17,7 @@ lib = N.lib()
 bad = 0
 worst = 0.0
 for c in range(cases):
-    D = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 12, 16, 17, 31, 32, 33, 48, 63, 64, 65, 100, 128, 130]))
+    D = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 12, 16, 17, 20, 31, 32, 33, 48, 63, 64, 65, 100, 128, 130, 256, 257, 300, 768, 1000, 1024, 1030]))
     K = int(rng.choice([1, 2, 3, 7, 8, 9, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 250, 255, 256, 257, 600, 1000, 1031]))
     B = int(rng.integers(1, max(2, min(400, 2_000_000 // (K * D)))))
     mu = (rng.standard_normal((B, D)) * rng.choice([0.1, 1.0, 3.0])).astype(np.float32)
@@ -65,7 +65,8 @@ for c in range(cases):
         errs.append(("iw_ll", np.abs(iw.cpu().numpy() - iw_ref).max() / scale))
     for name, e in errs:
         worst = max(worst, float(e)) if np.isfinite(e) else worst
-        if not np.isfinite(e) or e > 1e-6:
+        # (D > 1024 takes the one-lane-per-row kernel: a serial float32 sum over the row, ~2e-6)
+        if not np.isfinite(e) or e > (4e-6 if D > 1024 else 1e-6):
             print(f"FAIL {name} rel err {e:.3e}  {tag}", flush=True)
             bad += 1
     if (c + 1) % 50 == 0:
