@@ -78,10 +78,13 @@ template <int DCT>
 __global__ void __launch_bounds__(256)
 pair_pm_kernel(const float* __restrict__ z, const float* __restrict__ dparams,
                float2* __restrict__ partial_pm, int* __restrict__ redo_flags, int64_t C, int64_t cpad,
-               int64_t R, int64_t rows_per_split, int D, int DC, int d0,
+               int64_t R, int64_t rows_per_split, int D, int DC, int d0_base,
                const PairHeader* __restrict__ hdr, float cond_limit) {
     // cond_limit >= 0: the matrix-pipe form (pair_pm_bx_kernel) covers well-conditioned inputs, this one the rest
     if (cond_limit >= 0.f && !(__uint_as_float(hdr->cond_bits) > cond_limit)) return;
+    // blockIdx.z: the DCT-wide chunk of the latent row (all chunks of a wide row in ONE launch: D = 768 used to be
+    // 24 launches of a grid that a training batch does not fill)
+    const int d0 = d0_base + (int)blockIdx.z * DCT;
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = col < C ? col : C - 1;
     const int64_t j0 = (int64_t)blockIdx.y * rows_per_split;
@@ -340,8 +343,8 @@ static int launch_joint(const PairPlan& p, const float* z, const float* dparams,
 
 template <int DCT>
 static int launch_pm(const PairPlan& p, const float* z, const float* dparams, float2* partial_pm,
-                     int* redo_flags, int d0, const PairHeader* hdr, float pm_cond_limit, hipStream_t st) {
-    const dim3 grid((unsigned)(p.cpad / 256), (unsigned)p.dsplit);
+                     int* redo_flags, int d0, int chunks, const PairHeader* hdr, float pm_cond_limit, hipStream_t st) {
+    const dim3 grid((unsigned)(p.cpad / 256), (unsigned)p.dsplit, (unsigned)chunks);
     hipLaunchKernelGGL((pair_pm_kernel<DCT>), grid, dim3(256), 0, st, z, dparams, partial_pm, redo_flags,
                        p.C, p.cpad, p.R, p.rows_per_dsplit, p.D, p.DC, d0, hdr, pm_cond_limit);
     LVAE_LAUNCH_CHECK();
@@ -387,9 +390,11 @@ int lvae_launch_pair_direct(const PairPlan& p, bool joint, bool pm, const float*
     if (pm) {
         // per-dimension states are independent: latent rows wider than 32 are swept in 32-wide chunks
         int zper = DC >= 32 ? 2 : 1;
-        for (int d0 = 0; d0 < DC && !pm_fast_done; d0 += 32) {   // (pm_fast_done: another kernel wrote partials + flags)
-            if (DC - d0 >= 32) rc = launch_pm<32>(p, z, dparams, partial_pm, redo_flags, d0, hdr, pm_cond_limit, st);
-            else rc = launch_pm<16>(p, z, dparams, partial_pm, redo_flags, d0, hdr, pm_cond_limit, st);
+        if (!pm_fast_done) {                                      // (pm_fast_done: another kernel wrote partials + flags)
+            const int full = DC / 32;
+            if (full > 0) rc = launch_pm<32>(p, z, dparams, partial_pm, redo_flags, 0, full, hdr, pm_cond_limit, st);
+            if (rc != LVAE_OK) return rc;
+            if (DC % 32) rc = launch_pm<16>(p, z, dparams, partial_pm, redo_flags, full * 32, 1, hdr, pm_cond_limit, st);
             if (rc != LVAE_OK) return rc;
         }
         // DC % 32 == 16: the last fast launch covers one group, and its flag sits at that group's index,
