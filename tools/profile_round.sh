@@ -46,4 +46,5 @@ step "IW, small problems, training tail (no trace)"
 timeout -k 10 200 python3 $R/tools/bench_iw.py > "$OUT/iw.log" 2>&1 || exit 1
 timeout -k 10 200 python3 $R/tools/bench_small.py > "$OUT/small.log" 2>&1 || exit 1
 timeout -k 10 200 python3 $R/tools/bench_train_tail.py > "$OUT/train_tail.log" 2>&1 || exit 1
+timeout -k 10 300 python3 $R/tools/bench_wide.py > "$OUT/wide.log" 2>&1 || exit 1
 step "done"

@@ -24,7 +24,7 @@ for name, out in (("trace_bench", "kernel_stats_bench_n1.csv"), ("trace_paths", 
         shutil.copy(f, os.path.join(dst, out))
 texts = []
 for log in ("paths.log", "pm.log", "pm_bx.log", "perm.log", "bf16x3.log", "bwd.log", "iw.log", "iw_c5_iw.log", "iw_c5_dens.log",
-            "iw_c5_z.log", "small.log", "train_tail.log"):
+            "iw_c5_z.log", "small.log", "train_tail.log", "wide.log"):
     p = os.path.join(src, log)
     if os.path.exists(p):
         texts += [f"## {log}"] + [l.rstrip() for l in open(p) if not l.startswith(("W2", "E2", "I2")) and "amdgpu.ids" not in l]
