@@ -444,6 +444,125 @@ sample_iw_waverow_kernel(const float* __restrict__ mu, const float* __restrict__
     }
 }
 
+// Short rows outside the vector kernel's envelope (D / 4 not a power of two: 20, 36, 48, 100 ...): G lanes per row with
+// G the next power of two at or above the row's 16-byte pieces (VEC: D % 4 == 0, D <= 256) or elements (D <= 64), the
+// lanes past the end of the row idle (5 of 8 at D = 20, 25 of 32 at D = 100); 256 / G rows per workgroup pass, four
+// passes in flight, a butterfly over the G lanes per row.  (The wave-per-row kernel above keeps 5 of 64 lanes busy at
+// D = 20: 0.29 TB/s.)
+template <bool FROM_EPS, bool VEC>
+__global__ void __launch_bounds__(256)
+sample_iw_group_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                       const float* __restrict__ src, const float* __restrict__ log_p_x_z, int64_t K,
+                       int D, int G, float* __restrict__ z_out, float* __restrict__ log_q_z_x,
+                       float* __restrict__ log_p_z, float* __restrict__ iw_ll) {
+    constexpr int W = VEC ? 4 : 1;
+    constexpr int U = 4;                          // row passes in flight
+    const int64_t b = blockIdx.x;
+    const int gl = threadIdx.x & (G - 1), rsub = threadIdx.x / G, RP = 256 / G;
+    const int d0 = gl * W;
+    const bool active = d0 < D;
+    const bool have_post = mu != nullptr;
+    float m[W], sd[W], var[W];
+    float cq = 0.f, cp = 0.f;
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+        m[e] = 0.f;
+        sd[e] = 1.f;
+        var[e] = 1.f;
+        if (active) {
+            cp += -0.5f * LVAE_LOG_2PI;
+            if (have_post) {
+                const float lv = logvar[b * D + d0 + e];
+                m[e] = mu[b * D + d0 + e];
+                sd[e] = expf(0.5f * lv);
+                var[e] = expf(lv);
+                cq += -0.5f * (lv + LVAE_LOG_2PI);
+            }
+        }
+    }
+    float lm = -INFINITY, ls = 0.f;
+    for (int64_t k0 = 0; k0 < K; k0 += (int64_t)U * RP) {
+        float v[U][W];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t k = k0 + u * RP + rsub;
+#pragma unroll
+            for (int e = 0; e < W; ++e) v[u][e] = 0.f;
+            if (active && k < K) {
+                const float* __restrict__ row = src + (b * K + k) * D + d0;
+                if (VEC) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(row);
+#pragma unroll
+                    for (int e = 0; e < W; ++e) v[u][e] = t[e];
+                } else {
+                    v[u][0] = row[0];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t k = k0 + u * RP + rsub;
+            const bool ok = k < K;                 // (uniform over the G lanes of a row)
+            float zz[W], q = 0.f, p = 0.f;
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                zz[e] = (FROM_EPS && have_post) ? __fadd_rn(m[e], __fmul_rn(v[u][e], sd[e])) : v[u][e];
+                if (have_post) {
+                    const float df = zz[e] - m[e];
+                    q += __fdiv_rn(df * df, var[e]);
+                }
+                p = fmaf(zz[e], zz[e], p);
+            }
+            if (FROM_EPS && z_out && active && ok) {
+                float* __restrict__ zrow = z_out + (b * K + k) * D + d0;
+                if (VEC) {
+                    f32x4 t;
+#pragma unroll
+                    for (int e = 0; e < W; ++e) t[e] = zz[e];
+                    *reinterpret_cast<f32x4*>(zrow) = t;
+                } else {
+                    zrow[0] = zz[0];
+                }
+            }
+            float lq = active ? cq - 0.5f * q : 0.f;      // (idle lanes: zz = v = 0, their shares are zero)
+            float lp = active ? cp - 0.5f * p : 0.f;
+            for (int o = G >> 1; o >= 1; o >>= 1) {
+                lq += __shfl_xor(lq, o, 64);
+                lp += __shfl_xor(lp, o, 64);
+            }
+            if (!have_post) lq = 0.f;
+            if (gl == 0 && ok) {
+                if (log_q_z_x) log_q_z_x[b * K + k] = lq;
+                if (log_p_z) log_p_z[b * K + k] = lp;
+                if (iw_ll) lse_push(lm, ls, (log_p_x_z ? log_p_x_z[b * K + k] : 0.f) + lp - lq);
+            }
+        }
+    }
+    if (iw_ll) {
+        // merge the (max, sum) pairs of the row-owning lanes: butterfly over the wave, then the four waves
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float m2 = __shfl_xor(lm, o, 64), s2 = __shfl_xor(ls, o, 64);
+            const float mx = fmaxf(lm, m2);
+            ls = (ls > 0.f ? ls * __expf(lm - mx) : 0.f) + (s2 > 0.f ? s2 * __expf(m2 - mx) : 0.f);
+            lm = mx;
+        }
+        __shared__ float sm_m[4], sm_s[4];
+        if ((threadIdx.x & 63) == 0) {
+            sm_m[threadIdx.x >> 6] = lm;
+            sm_s[threadIdx.x >> 6] = ls;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float mx = -INFINITY;
+            for (int t = 0; t < 4; ++t) mx = fmaxf(mx, sm_m[t]);
+            double s2 = 0.0;
+            for (int t = 0; t < 4; ++t)
+                if (sm_s[t] > 0.f) s2 += (double)sm_s[t] * exp((double)sm_m[t] - (double)mx);
+            iw_ll[b] = (float)((double)mx + log(s2) - log((double)K));
+        }
+    }
+}
+
 // Element-wise (no latent reduction): sample_log_likelihood(..., reduce_latent_dim=False).
 __global__ void __launch_bounds__(256)
 sample_ll_elem_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
@@ -603,6 +722,19 @@ int lvae_launch_sample_iw(bool from_eps, const float* mu, const float* logvar, c
     } else if (D <= 1024 && !lvae_switches().iw_no_stage) {
         // (D % 4 == 0 makes every row 16-byte aligned: the tensors are whole allocations or 16-byte aligned views)
         const bool vec = D % 4 == 0 && (((uintptr_t)src | (uintptr_t)z_out) & 15) == 0;
+        const int pieces = vec ? D / 4 : D;
+        if (pieces <= 64) {                       // short rows: G lanes per row, G = next power of two
+            int Gp = 1;
+            while (Gp < pieces) Gp <<= 1;
+#define LVAE_SIWG(E, V)                                                                                            \
+    hipLaunchKernelGGL((sample_iw_group_kernel<E, V>), grid, dim3(256), 0, st, mu, logvar, src, log_p_x_z, K, D, Gp,   \
+                       z_out, log_q_z_x, log_p_z, iw_ll)
+            if (from_eps) { if (vec) LVAE_SIWG(true, true); else LVAE_SIWG(true, false); }
+            else { if (vec) LVAE_SIWG(false, true); else LVAE_SIWG(false, false); }
+#undef LVAE_SIWG
+            LVAE_LAUNCH_CHECK();
+            return LVAE_OK;
+        }
 #define LVAE_SIWR(E, V)                                                                                              \
     hipLaunchKernelGGL((sample_iw_waverow_kernel<E, V>), grid, dim3(256), 0, st, mu, logvar, src, log_p_x_z, K, D, z_out, \
                        log_q_z_x, log_p_z, iw_ll)
