@@ -1104,11 +1104,20 @@ extern "C" int lvae_latent_sums_f32(const float* z, const float* mu, const float
 // ---- MI bounds ---------------------------------------------------------------------------------------
 static size_t bounds_tail_bytes(int64_t K) { return lvae_align256((size_t)K * 3 * sizeof(float)); }
 
+// The two log q(z) calls of the bounds (all pairs / diagonal excluded) plan differently at D in (32, 64] -- two column
+// blocks per wave without the excluded diagonal, one with it or on the split-bf16 contraction --: the region is sized
+// for the larger plan.  (It used to be sized for the excluded-diagonal plan alone: K = 20,000 at D = 64 was refused
+// with "workspace too small" by the first call.)
+static size_t bounds_plan_bytes(int64_t K, int D) {
+    const size_t a = lvae_log_qz_plan(K, K, D, false, false, false).total;
+    const size_t b = lvae_log_qz_plan(K, K, D, false, true, true).total;
+    return a > b ? a : b;
+}
+
 extern "C" int lvae_pair_bounds_workspace_bytes(int64_t K, int D, int64_t* out_bytes) {
     LVAE_CHECK_ARG(out_bytes, "out_bytes is NULL");
     LVAE_CHECK_ARG(K >= 2 && D >= 1 && D <= 4096, "need K >= 2 and 1 <= D <= 4096");
-    const PairPlan p = lvae_make_pair_plan(K, K, D, false, 0, false, true);
-    *out_bytes = (int64_t)(p.total + bounds_tail_bytes(K));
+    *out_bytes = (int64_t)(bounds_plan_bytes(K, D) + bounds_tail_bytes(K));
     return LVAE_OK;
 }
 
@@ -1119,16 +1128,16 @@ extern "C" int lvae_pair_bounds_f32(const float* z, const float* mu, const float
     int rc = check_pair_shapes(z, mu, var, LVAE_SPREAD_VAR, K, K, D);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const PairPlan p = lvae_make_pair_plan(K, K, D, false, 0, false, true);
-    rc = check_ws(ws, ws_bytes, p.total + bounds_tail_bytes(K));
+    const size_t plan_bytes = bounds_plan_bytes(K, D);
+    rc = check_ws(ws, ws_bytes, plan_bytes + bounds_tail_bytes(K));
     if (rc) return rc;
-    float* tail = (float*)((char*)ws + p.total);
+    float* tail = (float*)((char*)ws + plan_bytes);
     float *diag = tail, *lse_all = tail + K, *lse_off = tail + 2 * K;
     rc = run_log_qz(z, mu, var, LVAE_SPREAD_VAR, K, K, D, logf((float)K), 0, 0, path, lse_all, nullptr,
-                    nullptr, nullptr, ws, (int64_t)p.total, st);
+                    nullptr, nullptr, ws, (int64_t)plan_bytes, st);
     if (rc) return rc;
     rc = run_log_qz(z, mu, var, LVAE_SPREAD_VAR, K, K, D, logf((float)(K - 1)), 1, 0, path, lse_off, nullptr,
-                    nullptr, nullptr, ws, (int64_t)p.total, st);
+                    nullptr, nullptr, ws, (int64_t)plan_bytes, st);
     if (rc) return rc;
     rc = lvae_launch_diag_ll(z, mu, var, LVAE_SPREAD_VAR, K, D, diag, st);
     if (rc) return rc;

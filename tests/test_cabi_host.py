@@ -255,6 +255,22 @@ def test_mmd_workspace_queries_cover_the_layout_of_every_mode():
                 assert info[0] <= out.value, ("mmd_rbf", na, nb, D, which)
 
 
+def test_pair_bounds_workspace_covers_both_of_its_log_qz_calls():
+    """lvae_pair_bounds_f32 runs log q(z) twice -- all pairs, then with the diagonal excluded -- and the two calls plan
+    differently at D in (32, 64]; its workspace query must cover the larger plan (K = 20,000 at D = 64 was refused by
+    the first call when the region was sized for the excluded-diagonal plan alone)."""
+    from lvae import _native as N
+    lib = N.lib()
+    rng = np.random.default_rng(11)
+    a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+    shapes = [(20000, 64), (20000, 32), (20000, 128), (2, 1), (333, 768)]
+    shapes += [(int(rng.integers(2, 60000)), int(rng.integers(1, 200))) for _ in range(3000)]
+    for K, D in shapes:
+        N.check(lib.lvae_pair_bounds_workspace_bytes(K, D, a))
+        N.check(lib.lvae_log_qz_workspace_bytes(K, K, D, 0, b))
+        assert a.value >= b.value + 3 * 4 * K, (K, D, a.value, b.value)
+
+
 def test_backward_workspace_query_covers_both_gradient_modes():
     """lvae_log_qz_bwd_f32 picks its path from the gradients it is given; a workspace sized with prod_marginals = 1
     must also serve the call that passes g_log_qz alone (the matrix-core sweeps' region)."""
