@@ -290,6 +290,86 @@ pair_direct_wide_kernel(const float* __restrict__ z, const float* __restrict__ d
     if (col < C) partial[(int64_t)blockIdx.y * cpad + col] = make_float2(mv, sv);
 }
 
+// Wide rows, FEW kept elements (training batches: C <= 512): a lane per sample leaves the chip empty -- 32 samples at
+// D = 768 are one partly filled wave walking 32 x 768 terms, 0.39 ms.  Here a WAVE owns SPW samples and its lanes run
+// along the latent row (dimension lane + 64 s in register s): the posterior's parameters are read coalesced, once per
+// posterior for the wave's SPW samples, three vector instructions per 64 terms and a butterfly per (sample, posterior).
+// C / SPW waves x the plan's posterior splits.
+template <int SPW>
+__global__ void __launch_bounds__(256)
+pair_direct_rowwave_kernel(const float* __restrict__ z, const float* __restrict__ dparams,
+                           float2* __restrict__ partial, const PairHeader* __restrict__ hdr,
+                           float cond_limit, int use_if_above, int64_t C, int64_t cpad, int64_t R,
+                           int64_t rows_per_split, int D, int DC, int excl, int64_t excl_offset) {
+    if (cond_limit >= 0.f) {
+        const float cond = __uint_as_float(hdr->cond_bits);
+        if ((cond > cond_limit) != (use_if_above != 0)) return;
+    }
+    constexpr int MAXS = 16;                      // DC <= 1024
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * SPW;
+    if (i0 >= C) return;
+    float zr[SPW][MAXS];
+#pragma unroll
+    for (int q = 0; q < SPW; ++q)
+#pragma unroll
+        for (int sx = 0; sx < MAXS; ++sx) {
+            const int d = sx * 64 + lane;
+            zr[q][sx] = (d < D && i0 + q < C) ? z[(i0 + q) * D + d] : 0.f;
+        }
+    float mv[SPW], sv[SPW];
+#pragma unroll
+    for (int q = 0; q < SPW; ++q) {
+        mv[q] = DLSE_MINIT;
+        sv[q] = 0.f;
+    }
+    const int64_t j0 = (int64_t)blockIdx.y * rows_per_split;
+    int64_t j1 = j0 + rows_per_split;
+    if (j1 > R) j1 = R;
+    for (int64_t j = j0; j < j1; ++j) {
+        const float* __restrict__ pm = dparams + (j * 3 + 0) * DC;
+        const float* __restrict__ pw = dparams + (j * 3 + 1) * DC;
+        const float* __restrict__ pb = dparams + (j * 3 + 2) * DC;
+        float acc[SPW];
+#pragma unroll
+        for (int q = 0; q < SPW; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int sx = 0; sx < MAXS; ++sx) {
+            const int d = sx * 64 + lane;
+            if (sx * 64 < DC) {                   // (uniform)
+                float m = 0.f, w = 0.f, bb = 0.f;
+                if (d < DC) {
+                    m = pm[d];
+                    w = pw[d];
+                    bb = pb[d];
+                }
+#pragma unroll
+                for (int q = 0; q < SPW; ++q) {
+                    const float y = (zr[q][sx] - m) * w;
+                    acc[q] += fmaf(-y, y, bb);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < SPW; ++q) {
+            float v = wave_sum(acc[q]);
+            if (excl && j == i0 + q + excl_offset) v = -INFINITY;
+            const float xv = v - mv[q];
+            if (xv > DLSE_THR) {                  // (uniform: every lane holds the same v)
+                sv[q] = sv[q] * lvae_exp2(-xv) + 1.0f;
+                mv[q] = v;
+            } else {
+                sv[q] += lvae_exp2(xv);
+            }
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < SPW; ++q)
+            if (i0 + q < C) partial[(int64_t)blockIdx.y * cpad + i0 + q] = make_float2(mv[q], sv[q]);
+    }
+}
+
 // Any latent size: the sample row is re-read from global memory (L1/L2 resident) for every posterior.
 __global__ void __launch_bounds__(256)
 pair_direct_generic_kernel(const float* __restrict__ z, const float* __restrict__ dparams,
@@ -375,7 +455,17 @@ int lvae_launch_pair_direct(const PairPlan& p, bool joint, bool pm, const float*
             const dim3 grid((unsigned)(p.cpad / 256), (unsigned)p.dsplit);
             // (LVAE_DIRECT_GENERIC=1, read once per process: the one-row-at-a-time kernel, for comparisons)
             static const bool force_generic = getenv("LVAE_DIRECT_GENERIC") != nullptr;
-            if (DC % 16 == 0 && !force_generic)
+            if (DC <= 1024 && p.C <= 512 && !force_generic) {
+                // few kept elements: a wave per sample (one per wave up to 128 samples, four beyond)
+                if (p.C <= 128)
+                    hipLaunchKernelGGL((pair_direct_rowwave_kernel<1>), dim3((unsigned)lvae_ceil_div(p.C, 4), (unsigned)p.dsplit),
+                                       dim3(256), 0, st, z, dparams, partial, hdr, cond_limit, use_if_above, p.C, p.cpad, p.R,
+                                       p.rows_per_dsplit, p.D, DC, excl, excl_offset);
+                else
+                    hipLaunchKernelGGL((pair_direct_rowwave_kernel<4>), dim3((unsigned)lvae_ceil_div(p.C, 16), (unsigned)p.dsplit),
+                                       dim3(256), 0, st, z, dparams, partial, hdr, cond_limit, use_if_above, p.C, p.cpad, p.R,
+                                       p.rows_per_dsplit, p.D, DC, excl, excl_offset);
+            } else if (DC % 16 == 0 && !force_generic)
                 hipLaunchKernelGGL((pair_direct_wide_kernel<32>), grid, dim3(256), 0, st, z, dparams, partial,
                                    hdr, cond_limit, use_if_above, p.C, p.cpad, p.R, p.rows_per_dsplit, p.D,
                                    DC, excl, excl_offset);
