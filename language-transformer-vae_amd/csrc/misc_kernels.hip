@@ -224,6 +224,51 @@ pair_matrix_kernel(const float* __restrict__ a, const float* __restrict__ spread
                    const PairHeader* __restrict__ hdr, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
     const int64_t j = (int64_t)blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (mode == 0 && D > 32) {
+        // Rows wider than 32: the 16 x 16 tile's operands travel through LDS 64 dimensions at a time, read coalesced,
+        // with the variance, its logarithm and its reciprocal formed ONCE per (j, d) instead of once per (i, j, d) --
+        // a thread walking its own pair of rows with an exponential, a logarithm and a division per element took
+        // 124 us for a 32 x 32 matrix at D = 768.
+        __shared__ float sa[16][65], sb[16][65], si[16][65], sl[16][65];
+        __shared__ float slv[16];
+        const int tid = threadIdx.x, ti = tid & 15, tj = tid >> 4;
+        float acc = 0.f, lvsum = 0.f;
+        for (int d0 = 0; d0 < D; d0 += 64) {
+            __syncthreads();
+            for (int e = tid; e < 16 * 64; e += 256) {
+                const int r = e >> 6, c = e & 63, d = d0 + c;
+                const int64_t jj = (int64_t)blockIdx.y * 16 + r, ii = (int64_t)blockIdx.x * 16 + r;
+                float av = 0.f, iv = 0.f, lv = 0.f, bv = 0.f;
+                if (d < D && jj < na) {
+                    const float sp = spread[jj * D + d];
+                    const float var = spread_kind == LVAE_SPREAD_VAR ? sp : expf(sp);
+                    lv = (spread_kind == LVAE_SPREAD_VAR ? logf(sp) : sp) + LVAE_LOG_2PI;
+                    iv = 1.0f / var;
+                    av = a[jj * D + d];
+                }
+                if (d < D && ii < nb) bv = b[ii * D + d];
+                sa[r][c] = av;
+                si[r][c] = iv;
+                sl[r][c] = lv;
+                sb[r][c] = bv;
+            }
+            __syncthreads();
+            if (tid < 16) {                        // the chunk's share of sum_d (log var + log 2 pi), one thread per j
+                float t = 0.f;
+                for (int c = 0; c < 64; ++c) t += sl[tid][c];
+                slv[tid] = t;
+            }
+            __syncthreads();
+            lvsum += slv[tj];
+#pragma unroll 8
+            for (int c = 0; c < 64; ++c) {
+                const float df = sb[ti][c] - sa[tj][c];
+                acc = fmaf(df * df, si[tj][c], acc);
+            }
+        }
+        if (i < nb && j < na) out[j * nb + i] = -0.5f * (acc + lvsum);
+        return;
+    }
     if (i >= nb || j >= na) return;
     if (mode == 0) {
         float acc = 0.f;
