@@ -222,7 +222,7 @@ pair_direct_wide_kernel(const float* __restrict__ z, const float* __restrict__ d
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = col < C ? col : C - 1;
     const float* __restrict__ zi = z + i * D;
-    const bool vec4 = (D & 3) == 0;          // 16-byte loads of the row (rows are then 16-byte aligned)
+    const bool vec4 = (D & 3) == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0;   // 16-byte loads of 16-byte aligned rows
     float mv = DLSE_MINIT, sv = 0.f;
     const int64_t j0 = (int64_t)blockIdx.y * rows_per_split;
     int64_t j1 = j0 + rows_per_split;
