@@ -78,11 +78,13 @@ def test_reparam_iw_vs_c_oracle_large():
     np.testing.assert_allclose(out1["iw_ll"].cpu().numpy(), w, rtol=1e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize("D", [4, 8, 16, 32, 64, 128, 256, 20])
+@pytest.mark.parametrize("D", [4, 8, 16, 32, 64, 128, 256, 20, 48, 100, 30, 7, 300, 768, 1030])
 def test_reparam_iw_row_geometries(D):
     """Every lane-group width of the row reduction (G = D/4 = 1 ... 64 lanes: quad permutations, half-row mirror,
-    row rotation, cross-row shuffles; D = 20 takes the generic kernel) and both output routes -- [B,K] rows staged
-    through LDS (K a multiple of 4 from 256) and written piecewise (other K) -- against the C oracle."""
+    row rotation, cross-row shuffles) and both output routes -- [B,K] rows staged through LDS (K a multiple of 4 from
+    256) and written piecewise (other K) -- against the C oracle; and the latent sizes outside that kernel: short rows
+    on the next power of two of lanes (D = 20, 48, 100 by 16-byte pieces; 30, 7 by elements), long ones on a wave per
+    row (300, 768), beyond 1,024 one lane per row (1030)."""
     from lvae import estimators as E
     from oracle import oracle_c
     rng = np.random.default_rng(D)
