@@ -46,5 +46,6 @@ step "IW, small problems, training tail (no trace)"
 timeout -k 10 200 python3 $R/tools/bench_iw.py > "$OUT/iw.log" 2>&1 || exit 1
 timeout -k 10 200 python3 $R/tools/bench_small.py > "$OUT/small.log" 2>&1 || exit 1
 timeout -k 10 200 python3 $R/tools/bench_train_tail.py > "$OUT/train_tail.log" 2>&1 || exit 1
-timeout -k 10 300 python3 $R/tools/bench_wide.py > "$OUT/wide.log" 2>&1 || exit 1
+step "kernel trace of the wide-latent paths"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_wide" -o p -- python3 $R/tools/bench_wide.py > "$OUT/wide.log" 2>&1 || exit 1
 step "done"

@@ -18,7 +18,7 @@ for name, out in (("trace_bench", "kernel_stats_bench_n1.csv"), ("trace_paths", 
                   ("trace_bf16x3", "kernel_stats_bf16x3_comparison.csv"), ("trace_bwd", "kernel_stats_backward.csv"),
                   ("trace_iw_c5_iw", "kernel_stats_iw_c5_reduction_only.csv"),
                   ("trace_iw_c5_dens", "kernel_stats_iw_c5_with_densities.csv"),
-                  ("trace_iw_c5_z", "kernel_stats_iw_c5_with_z.csv")):
+                  ("trace_iw_c5_z", "kernel_stats_iw_c5_with_z.csv"), ("trace_wide", "kernel_stats_wide_latents.csv")):
     f = first(f"{name}/**/*kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(dst, out))
