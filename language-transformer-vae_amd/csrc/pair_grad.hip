@@ -200,6 +200,62 @@ grad_wide_sample_kernel(const float* __restrict__ z, const float* __restrict__ d
     d_z[i * D + d] = acc * (2.0f / LVAE_LOG2E);
 }
 
+// GW_JT samples per workgroup, the mirror image of grad_wide_posterior_shared_kernel below: every (m, w, b)_jd a thread
+// loads serves GW_JT samples, the joint weights of a chunk of 256 posteriors come from LDS.
+#define GW_JT 8
+__global__ void __launch_bounds__(256)
+grad_wide_sample_shared_kernel(const float* __restrict__ z, const float* __restrict__ dparams, const float* __restrict__ P,
+                               const float* __restrict__ log_qz, float log_norm, const float* __restrict__ g,
+                               const float* __restrict__ h, const float* __restrict__ lse2, int64_t M, int64_t N, int D,
+                               int DC, float* __restrict__ d_z, const PairHeader* __restrict__ gate_hdr, float cond_limit) {
+    if (gate_hdr && !(__uint_as_float(gate_hdr->cond_bits) > cond_limit)) return;
+    __shared__ float sW[GW_JT][256];
+    const int d = blockIdx.y * 256 + threadIdx.x;
+    const int64_t ibase = (int64_t)blockIdx.x * GW_JT;
+    const bool live = d < D;
+    const int dd = live ? d : D - 1;
+    float zi[GW_JT], hi[GW_JT], ls[GW_JT], gi[GW_JT], Li[GW_JT], acc[GW_JT];
+#pragma unroll
+    for (int q = 0; q < GW_JT; ++q) {
+        const int64_t i = ibase + q < M ? ibase + q : M - 1;
+        zi[q] = z[i * D + dd];
+        hi[q] = h ? h[i] : 0.f;
+        ls[q] = h ? lse2[i * DC + dd] : 0.f;
+        gi[q] = g ? g[i] : 0.f;
+        Li[q] = log_qz ? log_qz[i] + log_norm : 0.f;
+        acc[q] = 0.f;
+    }
+    for (int64_t j0 = 0; j0 < N; j0 += 256) {
+        const int64_t jt = j0 + threadIdx.x;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < GW_JT; ++q) {
+            const int64_t i = ibase + q < M ? ibase + q : M - 1;
+            sW[q][threadIdx.x] = (g && jt < N) ? gi[q] * __expf(P[jt * M + i] - Li[q]) : 0.f;
+        }
+        __syncthreads();
+        const int cnt = (int)(N - j0 < 256 ? N - j0 : 256);
+#pragma unroll 2
+        for (int t = 0; t < cnt; ++t) {
+            const int64_t j = j0 + t;
+            const float m = dparams[(j * 3 + 0) * DC + dd];
+            const float w = dparams[(j * 3 + 1) * DC + dd];
+            const float b = dparams[(j * 3 + 2) * DC + dd];
+#pragma unroll
+            for (int q = 0; q < GW_JT; ++q) {
+                const float y = (zi[q] - m) * w;
+                float G = sW[q][t];
+                if (h) G = fmaf(hi[q], lvae_exp2(fmaf(-y, y, b) - ls[q]), G);
+                acc[q] = fmaf(-(G * w), y, acc[q]);
+            }
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int q = 0; q < GW_JT; ++q)
+        if (ibase + q < M) d_z[(ibase + q) * D + d] = acc[q] * (2.0f / LVAE_LOG2E);
+}
+
 __global__ void __launch_bounds__(256)
 grad_wide_posterior_kernel(const float* __restrict__ z, const float* __restrict__ dparams,
                            const float* __restrict__ P, const float* __restrict__ log_qz, float log_norm,
@@ -227,16 +283,86 @@ grad_wide_posterior_kernel(const float* __restrict__ z, const float* __restrict_
     if (d_logvar) d_logvar[j * D + d] = dlv;
 }
 
+// The same sweep for GW_JT posteriors per workgroup: a thread owns one dimension of all of them, so every z_id and
+// lse_id it loads serves GW_JT posteriors (with one posterior per workgroup every posterior re-read the whole of z and of
+// the per-dimension logsumexps from L2: 103 GB at B = 4,096, D = 768, which was the kernel's time), and the joint
+// weights g_i exp(P_ji - L_i) -- identical for every dimension -- are formed once per workgroup and 256 samples (thread
+// t takes sample i0 + t) and read back from LDS together with h_i.
+__global__ void __launch_bounds__(256)
+grad_wide_posterior_shared_kernel(const float* __restrict__ z, const float* __restrict__ dparams,
+                                  const float* __restrict__ P, const float* __restrict__ log_qz, float log_norm,
+                                  const float* __restrict__ g, const float* __restrict__ h,
+                                  const float* __restrict__ lse2, int64_t M, int64_t N, int D, int DC,
+                                  float* __restrict__ d_mu, float* __restrict__ d_logvar,
+                                  const PairHeader* __restrict__ gate_hdr, float cond_limit) {
+    if (gate_hdr && !(__uint_as_float(gate_hdr->cond_bits) > cond_limit)) return;
+    __shared__ float sW[GW_JT][256], sH[256];
+    const int d = blockIdx.y * 256 + threadIdx.x;
+    const int64_t jbase = (int64_t)blockIdx.x * GW_JT;
+    const bool live = d < D;
+    const int dd = live ? d : D - 1;
+    float m[GW_JT], w[GW_JT], b[GW_JT], dmu[GW_JT], dlv[GW_JT];
+#pragma unroll
+    for (int jj = 0; jj < GW_JT; ++jj) {
+        const int64_t j = jbase + jj < N ? jbase + jj : N - 1;
+        m[jj] = dparams[(j * 3 + 0) * DC + dd];
+        w[jj] = dparams[(j * 3 + 1) * DC + dd];
+        b[jj] = dparams[(j * 3 + 2) * DC + dd];
+        dmu[jj] = 0.f;
+        dlv[jj] = 0.f;
+    }
+    for (int64_t i0 = 0; i0 < M; i0 += 256) {
+        const int64_t it = i0 + threadIdx.x;
+        __syncthreads();
+        {
+            const bool ok = g && it < M;
+            const float gi = ok ? g[it] : 0.f, Li = ok ? log_qz[it] + log_norm : 0.f;
+#pragma unroll
+            for (int jj = 0; jj < GW_JT; ++jj) {
+                const int64_t j = jbase + jj < N ? jbase + jj : N - 1;
+                sW[jj][threadIdx.x] = ok ? gi * __expf(P[j * M + it] - Li) : 0.f;
+            }
+            sH[threadIdx.x] = (h && it < M) ? h[it] : 0.f;
+        }
+        __syncthreads();
+        const int cnt = (int)(M - i0 < 256 ? M - i0 : 256);
+#pragma unroll 2
+        for (int t = 0; t < cnt; ++t) {
+            const int64_t i = i0 + t;
+            const float zi = z[i * D + dd];
+            const float ls = h ? lse2[i * DC + dd] : 0.f;
+            const float hi = sH[t];
+#pragma unroll
+            for (int jj = 0; jj < GW_JT; ++jj) {
+                const float y = (zi - m[jj]) * w[jj];
+                float G = sW[jj][t];
+                if (h) G = fmaf(hi, lvae_exp2(fmaf(-y, y, b[jj]) - ls), G);
+                dmu[jj] = fmaf(G * w[jj], y, dmu[jj]);
+                dlv[jj] = fmaf(G, fmaf(y * (1.0f / LVAE_LOG2E), y, -0.5f), dlv[jj]);
+            }
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int jj = 0; jj < GW_JT; ++jj) {
+        const int64_t j = jbase + jj;
+        if (j < N) {
+            if (d_mu) d_mu[j * D + d] = dmu[jj] * (2.0f / LVAE_LOG2E);
+            if (d_logvar) d_logvar[j * D + d] = dlv[jj];
+        }
+    }
+}
+
 int lvae_launch_grad_wide(const float* z, const float* dparams, const float* P, const float* log_qz, float log_norm,
                           const float* g, const float* h, const float* lse2, int64_t M, int64_t N, int D, int DC,
                           float* d_z, float* d_mu, float* d_logvar, hipStream_t st, const PairHeader* gate_hdr,
                           float cond_limit) {
     const unsigned dy = (unsigned)lvae_ceil_div(D, 256);
     if (d_z)
-        hipLaunchKernelGGL(grad_wide_sample_kernel, dim3((unsigned)M, dy), dim3(256), 0, st, z, dparams, P, log_qz,
-                           log_norm, g, h, lse2, M, N, D, DC, d_z, gate_hdr, cond_limit);
+        hipLaunchKernelGGL(grad_wide_sample_shared_kernel, dim3((unsigned)lvae_ceil_div(M, GW_JT), dy), dim3(256), 0, st, z,
+                           dparams, P, log_qz, log_norm, g, h, lse2, M, N, D, DC, d_z, gate_hdr, cond_limit);
     if (d_mu || d_logvar)
-        hipLaunchKernelGGL(grad_wide_posterior_kernel, dim3((unsigned)N, dy), dim3(256), 0, st, z, dparams, P, log_qz,
+        hipLaunchKernelGGL(grad_wide_posterior_shared_kernel, dim3((unsigned)lvae_ceil_div(N, GW_JT), dy), dim3(256), 0, st, z, dparams, P, log_qz,
                            log_norm, g, h, lse2, M, N, D, DC, d_mu, d_logvar, gate_hdr, cond_limit);
     LVAE_LAUNCH_CHECK();
     return LVAE_OK;
