@@ -172,36 +172,8 @@ pair_grad_posterior_kernel(const float* __restrict__ dparams, const float* __res
 // The joint weight p_ij needs the density over ALL dimensions, which a (sample, dimension) thread does not see:
 // it is read from P [N][M], the explicit matrix of natural-log pair densities (pair_matrix_kernel, the layout of
 // lvae_log_prob_pairs_f32).  The prod-marginals weight r_ijd is local to the dimension.  No partials, no atomics.
-__global__ void __launch_bounds__(256)
-grad_wide_sample_kernel(const float* __restrict__ z, const float* __restrict__ dparams, const float* __restrict__ P,
-                        const float* __restrict__ log_qz, float log_norm, const float* __restrict__ g,
-                        const float* __restrict__ h, const float* __restrict__ lse2, int64_t M, int64_t N, int D,
-                        int DC, float* __restrict__ d_z, const PairHeader* __restrict__ gate_hdr, float cond_limit) {
-    if (gate_hdr && !(__uint_as_float(gate_hdr->cond_bits) > cond_limit)) return;
-    const int d = blockIdx.y * 256 + threadIdx.x;
-    const int64_t i = blockIdx.x;
-    if (d >= D) return;
-    const float zi = z[i * D + d];
-    const float L = log_qz ? log_qz[i] + log_norm : 0.f;
-    const float gi = g ? g[i] : 0.f;
-    const float hi = h ? h[i] : 0.f;
-    const float ls = h ? lse2[i * DC + d] : 0.f;
-    float acc = 0.f;
-    for (int64_t j = 0; j < N; ++j) {
-        const float m = dparams[(j * 3 + 0) * DC + d];
-        const float w = dparams[(j * 3 + 1) * DC + d];
-        const float b = dparams[(j * 3 + 2) * DC + d];
-        const float y = (zi - m) * w;
-        float G = 0.f;
-        if (g) G = gi * __expf(P[j * M + i] - L);
-        if (h) G = fmaf(hi, lvae_exp2(fmaf(-y, y, b) - ls), G);
-        acc = fmaf(-(G * w), y, acc);
-    }
-    d_z[i * D + d] = acc * (2.0f / LVAE_LOG2E);
-}
-
-// GW_JT samples per workgroup, the mirror image of grad_wide_posterior_shared_kernel below: every (m, w, b)_jd a thread
-// loads serves GW_JT samples, the joint weights of a chunk of 256 posteriors come from LDS.
+// Sample-side sweep, GW_JT samples per workgroup (the mirror image of grad_wide_posterior_shared_kernel below): every
+// (m, w, b)_jd a thread loads serves GW_JT samples, the joint weights of a chunk of 256 posteriors come from LDS.
 #define GW_JT 8
 __global__ void __launch_bounds__(256)
 grad_wide_sample_shared_kernel(const float* __restrict__ z, const float* __restrict__ dparams, const float* __restrict__ P,
@@ -256,34 +228,7 @@ grad_wide_sample_shared_kernel(const float* __restrict__ z, const float* __restr
         if (ibase + q < M) d_z[(ibase + q) * D + d] = acc[q] * (2.0f / LVAE_LOG2E);
 }
 
-__global__ void __launch_bounds__(256)
-grad_wide_posterior_kernel(const float* __restrict__ z, const float* __restrict__ dparams,
-                           const float* __restrict__ P, const float* __restrict__ log_qz, float log_norm,
-                           const float* __restrict__ g, const float* __restrict__ h,
-                           const float* __restrict__ lse2, int64_t M, int64_t N, int D, int DC,
-                           float* __restrict__ d_mu, float* __restrict__ d_logvar,
-                           const PairHeader* __restrict__ gate_hdr, float cond_limit) {
-    if (gate_hdr && !(__uint_as_float(gate_hdr->cond_bits) > cond_limit)) return;
-    const int d = blockIdx.y * 256 + threadIdx.x;
-    const int64_t j = blockIdx.x;
-    if (d >= D) return;
-    const float m = dparams[(j * 3 + 0) * DC + d];
-    const float w = dparams[(j * 3 + 1) * DC + d];
-    const float b = dparams[(j * 3 + 2) * DC + d];
-    float dmu = 0.f, dlv = 0.f;
-    for (int64_t i = 0; i < M; ++i) {
-        const float y = (z[i * D + d] - m) * w;
-        float G = 0.f;
-        if (g) G = g[i] * __expf(P[j * M + i] - (log_qz[i] + log_norm));
-        if (h) G = fmaf(h[i], lvae_exp2(fmaf(-y, y, b) - lse2[i * DC + d]), G);
-        dmu = fmaf(G * w, y, dmu);
-        dlv = fmaf(G, fmaf(y * (1.0f / LVAE_LOG2E), y, -0.5f), dlv);
-    }
-    if (d_mu) d_mu[j * D + d] = dmu * (2.0f / LVAE_LOG2E);
-    if (d_logvar) d_logvar[j * D + d] = dlv;
-}
-
-// The same sweep for GW_JT posteriors per workgroup: a thread owns one dimension of all of them, so every z_id and
+// The posterior-side sweep, GW_JT posteriors per workgroup: a thread owns one dimension of all of them, so every z_id and
 // lse_id it loads serves GW_JT posteriors (with one posterior per workgroup every posterior re-read the whole of z and of
 // the per-dimension logsumexps from L2: 103 GB at B = 4,096, D = 768, which was the kernel's time), and the joint
 // weights g_i exp(P_ji - L_i) -- identical for every dimension -- are formed once per workgroup and 256 samples (thread
