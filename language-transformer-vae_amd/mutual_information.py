@@ -150,6 +150,8 @@ def log_prob_pairs(dists, sample_batch):
 def _bounds(samples, dists, path=N.PATH_AUTO):
     mu, cov = _dists_to_params(dists)
     z, mu, cov = N.as_f32(samples.squeeze(), "samples"), N.as_f32(mu, "mu"), N.as_f32(cov, "cov")
+    if z.dim() == 1 and mu.dim() == 2 and mu.shape[1] == 1:
+        z = z.unsqueeze(1)          # latent_size 1: the reference's squeeze() (mutual_information.py:127) drops the axis
     K, D = z.shape
     dev = z.device
     with torch.cuda.device(dev):

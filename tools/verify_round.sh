@@ -12,6 +12,8 @@ timeout -k 10 300 python -u tests/fuzz_iw.py 400 5 > gpurun_out/r3v/fuzz_iw.log 
 tail -1 gpurun_out/r3v/fuzz_iw.log
 timeout -k 10 300 python -u tests/fuzz_tail.py 150 3 > gpurun_out/r3v/fuzz_tail.log 2>&1 || { tail -20 gpurun_out/r3v/fuzz_tail.log; exit 1; }
 tail -1 gpurun_out/r3v/fuzz_tail.log
+timeout -k 10 600 python -u tests/fuzz_api.py 100 9 > gpurun_out/r3v/fuzz_api.log 2>&1 || { tail -20 gpurun_out/r3v/fuzz_api.log; exit 1; }
+tail -1 gpurun_out/r3v/fuzz_api.log
 LVAE_BENCH_REHEARSAL=1 timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1 > gpurun_out/r3v/bench_torchrun2.log 2>&1 || { tail -20 gpurun_out/r3v/bench_torchrun2.log; exit 1; }
 grep '^{"metric"' gpurun_out/r3v/bench_torchrun2.log | cut -c1-300
 timeout -k 10 300 python bench.py > gpurun_out/r3v/bench.log 2>&1 || { tail -20 gpurun_out/r3v/bench.log; exit 1; }
